@@ -1,0 +1,456 @@
+// extern "C" entry points of libalabi_hip.so (declared in include/alabi_hip.h).
+#include <cmath>
+#include <cstdlib>
+#include <new>
+
+#include "gp_device.hpp"
+
+namespace alabi {
+thread_local std::string g_last_error;
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+__global__ void __launch_bounds__(256)
+copy_factor_kernel(const double* __restrict__ L, int ld, int N, double* __restrict__ out) {
+    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)N * N) return;
+    int r = (int)(e / N), c = (int)(e % N);
+    out[e] = (c <= r) ? L[(size_t)r * ld + c] : 0.0;
+}
+
+static int fill_dimvec(DimVec& v, const double* src, int d, int stride, int off, double pad) {
+    for (int k = 0; k < ALABI_MAX_DIM; ++k) v.v[k] = (k < d) ? src[k * stride + off] : pad;
+    return 0;
+}
+}  // namespace alabi
+
+using namespace alabi;
+
+extern "C" {
+
+int alabi_abi_version(void) { return 1; }
+
+const char* alabi_status_string(int status) {
+    switch (status) {
+        case ALABI_OK: return "ok";
+        case ALABI_NOT_POSITIVE_DEFINITE: return "matrix is not positive definite";
+        case ALABI_BAD_ARGUMENT: return "bad argument";
+        case ALABI_HIP_ERROR: return "HIP runtime error";
+        case ALABI_NOT_COMPUTED: return "GP not computed / y not set";
+        default: return "unknown status";
+    }
+}
+
+const char* alabi_last_error(void) { return g_last_error.c_str(); }
+
+int alabi_device_info(int* n_cu, int* lds_bytes, char* arch) {
+    int dev = 0;
+    ALABI_HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    ALABI_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int)prop.sharedMemPerBlock;
+    if (arch) { strncpy(arch, prop.gcnArchName, 63); arch[63] = 0; }
+    return ALABI_OK;
+}
+
+// ---------------------------------------------------------------------------------- GP
+int alabi_gp_create(int n_cap, int d, alabi_gp** out) {
+    if (!out || n_cap <= 0 || d <= 0 || d > ALABI_MAX_DIM) return ALABI_BAD_ARGUMENT;
+    alabi_gp* gp = new (std::nothrow) alabi_gp();
+    if (!gp) return ALABI_BAD_ARGUMENT;
+    gp->n_cap = round_up(n_cap, ALABI_BLK);
+    gp->d = d;
+    for (int k = 0; k < ALABI_MAX_DIM; ++k) { gp->log_M[k] = 0.0; gp->inv_len.v[k] = (k < d) ? 1.0 : 0.0; }
+    const size_t nc = gp->n_cap;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc(&gp->L, nc * nc * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&gp->Xt, (size_t)dim_bucket(d) * nc * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&gp->y, nc * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&gp->alpha, nc * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&gp->work, 2 * nc * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&gp->red, 4 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&gp->info, sizeof(int));
+    if (e != hipSuccess) {
+        alabi_gp_destroy(gp);
+        return hip_fail(e, "hipMalloc(gp buffers)", __FILE__, __LINE__);
+    }
+    *out = gp;
+    return ALABI_OK;
+}
+
+int alabi_gp_destroy(alabi_gp* gp) {
+    if (!gp) return ALABI_OK;
+    if (gp->L) (void)hipFree(gp->L);
+    if (gp->Xt) (void)hipFree(gp->Xt);
+    if (gp->y) (void)hipFree(gp->y);
+    if (gp->alpha) (void)hipFree(gp->alpha);
+    if (gp->work) (void)hipFree(gp->work);
+    if (gp->red) (void)hipFree(gp->red);
+    if (gp->info) (void)hipFree(gp->info);
+    if (gp->ws) (void)hipFree(gp->ws);
+    if (gp->scan) (void)hipFree(gp->scan);
+    delete gp;
+    return ALABI_OK;
+}
+
+int alabi_gp_set_hyper(alabi_gp* gp, double mean, double log_white_noise, double log_amp, const double* log_M) {
+    if (!gp || !log_M) return ALABI_BAD_ARGUMENT;
+    if (!std::isfinite(mean) || !std::isfinite(log_white_noise) || !std::isfinite(log_amp)) return ALABI_BAD_ARGUMENT;
+    for (int k = 0; k < gp->d; ++k)
+        if (!std::isfinite(log_M[k])) return ALABI_BAD_ARGUMENT;
+    gp->mean = mean; gp->log_wn = log_white_noise; gp->log_amp = log_amp;
+    for (int k = 0; k < gp->d; ++k) { gp->log_M[k] = log_M[k]; gp->inv_len.v[k] = std::exp(-0.5 * log_M[k]); }
+    gp->computed = false; gp->has_alpha = false; gp->gen++;
+    return ALABI_OK;
+}
+
+int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream) {
+    if (!gp || !X || N <= 0 || N > gp->n_cap) return ALABI_BAD_ARGUMENT;
+    hipStream_t s = as_stream(stream);
+    gp->N = N; gp->Npad = round_up(N, ALABI_BLK);
+    gp->computed = false; gp->has_alpha = false; gp->gen++;
+    int st;
+    if ((st = launch_prepare_inputs(gp, X, N, s)) != ALABI_OK) return st;
+    if ((st = launch_assemble(gp, s)) != ALABI_OK) return st;
+    if ((st = launch_cholesky(gp, s)) != ALABI_OK) return st;
+    int info = 0;
+    ALABI_HIP_CHECK(hipMemcpyAsync(&info, gp->info, sizeof(int), hipMemcpyDeviceToHost, s));
+    ALABI_HIP_CHECK(hipStreamSynchronize(s));
+    gp->last_pivot = info;
+    if (info != 0) return ALABI_NOT_POSITIVE_DEFINITE;
+    gp->computed = true;
+    return ALABI_OK;
+}
+
+int alabi_gp_last_pivot(alabi_gp* gp, int* pivot) {
+    if (!gp || !pivot) return ALABI_BAD_ARGUMENT;
+    *pivot = gp->last_pivot;
+    return ALABI_OK;
+}
+
+int alabi_gp_n(alabi_gp* gp, int* n) {
+    if (!gp || !n) return ALABI_BAD_ARGUMENT;
+    *n = gp->N;
+    return ALABI_OK;
+}
+
+int alabi_gp_set_y(alabi_gp* gp, const double* y, void* stream) {
+    if (!gp || !y) return ALABI_BAD_ARGUMENT;
+    if (!gp->computed) return ALABI_NOT_COMPUTED;
+    hipStream_t s = as_stream(stream);
+    ALABI_HIP_CHECK(hipMemcpyAsync(gp->y, y, (size_t)gp->N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    int st = launch_alpha(gp, s);
+    if (st != ALABI_OK) return st;
+    gp->has_alpha = true; gp->gen++;
+    return ALABI_OK;
+}
+
+int alabi_gp_predict(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var, void* stream) {
+    if (!gp || M < 0 || (M > 0 && (!Xs || !mu))) return ALABI_BAD_ARGUMENT;
+    if (!gp->computed || !gp->has_alpha) return ALABI_NOT_COMPUTED;
+    if (M == 0) return ALABI_OK;
+    hipStream_t s = as_stream(stream);
+    if (var) return launch_predict_var(gp, Xs, M, mu, var, s);
+    return launch_predict_mean(gp, Xs, M, mu, s);
+}
+
+static int gp_reductions_to_host(alabi_gp* gp, double out[2], hipStream_t s) {
+    int st = launch_reductions(gp, s);
+    if (st != ALABI_OK) return st;
+    ALABI_HIP_CHECK(hipMemcpyAsync(out, gp->red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    ALABI_HIP_CHECK(hipStreamSynchronize(s));
+    return ALABI_OK;
+}
+
+int alabi_gp_logdet(alabi_gp* gp, double* out, void* stream) {
+    if (!gp || !out) return ALABI_BAD_ARGUMENT;
+    if (!gp->computed) return ALABI_NOT_COMPUTED;
+    double r[2];
+    int st = gp_reductions_to_host(gp, r, as_stream(stream));
+    if (st != ALABI_OK) return st;
+    *out = r[0];
+    return ALABI_OK;
+}
+
+int alabi_gp_nll(alabi_gp* gp, double* out, void* stream) {
+    if (!gp || !out) return ALABI_BAD_ARGUMENT;
+    if (!gp->computed || !gp->has_alpha) return ALABI_NOT_COMPUTED;
+    double r[2];
+    int st = gp_reductions_to_host(gp, r, as_stream(stream));
+    if (st != ALABI_OK) return st;
+    *out = 0.5 * r[1] + 0.5 * r[0] + 0.5 * gp->N * std::log(2.0 * 3.141592653589793);
+    return ALABI_OK;
+}
+
+int alabi_gp_get_alpha(alabi_gp* gp, double* alpha_out, void* stream) {
+    if (!gp || !alpha_out) return ALABI_BAD_ARGUMENT;
+    if (!gp->computed || !gp->has_alpha) return ALABI_NOT_COMPUTED;
+    ALABI_HIP_CHECK(hipMemcpyAsync(alpha_out, gp->alpha, (size_t)gp->N * sizeof(double), hipMemcpyDeviceToDevice,
+                                   as_stream(stream)));
+    return ALABI_OK;
+}
+
+int alabi_gp_get_factor(alabi_gp* gp, double* L_out, void* stream) {
+    if (!gp || !L_out) return ALABI_BAD_ARGUMENT;
+    if (!gp->computed) return ALABI_NOT_COMPUTED;
+    size_t n2 = (size_t)gp->N * gp->N;
+    hipLaunchKernelGGL(copy_factor_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       gp->L, gp->Npad, gp->N, L_out);
+    ALABI_LAUNCH_CHECK();
+    return ALABI_OK;
+}
+
+int alabi_kernel_matrix(const double* X1, int n1, const double* X2, int n2, int d, double log_amp,
+                        const double* log_M, double* K_out, void* stream) {
+    if (!X1 || !X2 || !K_out || !log_M || n1 <= 0 || n2 <= 0 || d <= 0 || d > ALABI_MAX_DIM) return ALABI_BAD_ARGUMENT;
+    DimVec inv;
+    for (int k = 0; k < ALABI_MAX_DIM; ++k) inv.v[k] = (k < d) ? std::exp(-0.5 * log_M[k]) : 0.0;
+    return launch_kernel_matrix(X1, n1, X2, n2, d, std::exp(log_amp), inv, K_out, as_stream(stream));
+}
+
+// ----------------------------------------------------------------------------- utility
+int alabi_utility_eval(int algo, const double* Xs, long long M, int d, const double* bounds, double y_best,
+                       const double* mu, const double* var, double* u, void* stream) {
+    if (algo < 0 || algo > 2 || M < 0 || d <= 0 || d > ALABI_MAX_DIM || !bounds) return ALABI_BAD_ARGUMENT;
+    if (M == 0) return ALABI_OK;
+    if (!Xs || !mu || !var || !u) return ALABI_BAD_ARGUMENT;
+    DimVec lo, hi;
+    fill_dimvec(lo, bounds, d, 2, 0, 0.0);
+    fill_dimvec(hi, bounds, d, 2, 1, 0.0);
+    return launch_utility_eval(algo, Xs, M, d, lo, hi, y_best, mu, var, u, as_stream(stream));
+}
+
+int alabi_utility_scan(alabi_gp* gp, int algo, const double* Xs, long long M, const double* bounds, double y_best,
+                       double* u, double* mu_out, double* var_out, double* best_val, long long* best_idx,
+                       void* stream) {
+    if (!gp || algo < 0 || algo > 2 || M <= 0 || !Xs || !bounds || !best_val || !best_idx) return ALABI_BAD_ARGUMENT;
+    if (!gp->computed || !gp->has_alpha) return ALABI_NOT_COMPUTED;
+    hipStream_t s = as_stream(stream);
+    const int nblocks = 1024;
+    const size_t need = ((size_t)3 * M + 2 * nblocks) * sizeof(double);
+    if (need > gp->scan_bytes) {
+        if (gp->scan) {
+            ALABI_HIP_CHECK(hipStreamSynchronize(s));
+            ALABI_HIP_CHECK(hipFree(gp->scan));
+            gp->scan = nullptr; gp->scan_bytes = 0;
+        }
+        ALABI_HIP_CHECK(hipMalloc(&gp->scan, need));
+        gp->scan_bytes = need;
+    }
+    double* pv = gp->scan;
+    long long* pi = reinterpret_cast<long long*>(gp->scan + nblocks);
+    double* mu = mu_out ? mu_out : gp->scan + 2 * nblocks;
+    double* var = var_out ? var_out : gp->scan + 2 * nblocks + M;
+    double* uu = u ? u : gp->scan + 2 * nblocks + 2 * M;
+    int st;
+    if ((st = launch_predict_var(gp, Xs, M, mu, var, s)) != ALABI_OK) return st;
+    DimVec lo, hi;
+    fill_dimvec(lo, bounds, gp->d, 2, 0, 0.0);
+    fill_dimvec(hi, bounds, gp->d, 2, 1, 0.0);
+    if ((st = launch_utility_eval(algo, Xs, M, gp->d, lo, hi, y_best, mu, var, uu, s)) != ALABI_OK) return st;
+    if ((st = launch_argmin(uu, M, pv, pi, nblocks, s)) != ALABI_OK) return st;
+    double hv; long long hi_idx;
+    ALABI_HIP_CHECK(hipMemcpyAsync(&hv, pv, sizeof(double), hipMemcpyDeviceToHost, s));
+    ALABI_HIP_CHECK(hipMemcpyAsync(&hi_idx, pi, sizeof(long long), hipMemcpyDeviceToHost, s));
+    ALABI_HIP_CHECK(hipStreamSynchronize(s));
+    *best_idx = hi_idx;
+    *best_val = (hi_idx >= 0) ? hv : NAN;
+    return ALABI_OK;
+}
+
+// ---------------------------------------------------------------------------- ensemble
+int alabi_ens_create(alabi_gp* gp, int W, int d, const double* bounds, unsigned long long seed, alabi_ens** out) {
+    if (!gp || !out || !bounds || W < 2 || W > 8192 || d != gp->d) return ALABI_BAD_ARGUMENT;
+    alabi_ens* e = new (std::nothrow) alabi_ens();
+    if (!e) return ALABI_BAD_ARGUMENT;
+    e->gp = gp; e->W = W; e->d = d; e->seed = seed;
+    fill_dimvec(e->lo, bounds, d, 2, 0, 0.0);
+    fill_dimvec(e->hi, bounds, d, 2, 1, 0.0);
+    long long cap = (4LL << 20) / W;
+    if (cap > 1024) cap = 1024;
+    if (cap < 16) cap = 16;
+    e->chunk_cap = (int)cap;
+    const size_t n = (size_t)e->chunk_cap * W;
+    hipError_t err = hipSuccess;
+    if (err == hipSuccess) err = hipMalloc(&e->order, n * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&e->partner, n * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&e->u_z, n * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc(&e->u_acc, n * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc(&e->run_state, 4 * sizeof(long long));
+    if (err != hipSuccess) {
+        alabi_ens_destroy(e);
+        return hip_fail(err, "hipMalloc(ensemble buffers)", __FILE__, __LINE__);
+    }
+    *out = e;
+    return ALABI_OK;
+}
+
+int alabi_ens_destroy(alabi_ens* e) {
+    if (!e) return ALABI_OK;
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    if (e->order) (void)hipFree(e->order);
+    if (e->partner) (void)hipFree(e->partner);
+    if (e->u_z) (void)hipFree(e->u_z);
+    if (e->u_acc) (void)hipFree(e->u_acc);
+    if (e->run_state) (void)hipFree(e->run_state);
+    delete e;
+    return ALABI_OK;
+}
+
+int alabi_ens_lnprob(alabi_ens* e, const double* coords, double* logp, void* stream) {
+    if (!e || !coords || !logp) return ALABI_BAD_ARGUMENT;
+    if (!e->gp->computed || !e->gp->has_alpha) return ALABI_NOT_COMPUTED;
+    return launch_ens_lnprob(e, coords, e->W, logp, as_stream(stream));
+}
+
+static HalfArgs base_args(alabi_ens* e, double* coords, double* logp, double a) {
+    HalfArgs h{};
+    alabi_gp* gp = e->gp;
+    h.coords = coords; h.logp = logp;
+    h.Xt = gp->Xt; h.alpha = gp->alpha; h.Npad = gp->Npad;
+    h.amp = std::exp(gp->log_amp); h.mean = gp->mean;
+    h.W = e->W; h.d = e->d; h.n0 = (e->W + 1) / 2;
+    h.a = a; h.thin_by = 1; h.run_state = e->run_state;
+    return h;
+}
+
+static int set_run_state(alabi_ens* e, long long step0, long long done, hipStream_t s) {
+    long long host[2] = {step0, done};
+    ALABI_HIP_CHECK(hipMemcpyAsync(e->run_state, host, sizeof(host), hipMemcpyHostToDevice, s));
+    // the source is a stack buffer: make sure the copy has read it before returning
+    ALABI_HIP_CHECK(hipStreamSynchronize(s));
+    return ALABI_OK;
+}
+
+// enqueue `n` steps that consume the chunk buffers (draw + 2n half steps + advance)
+static int enqueue_chunk(alabi_ens* e, HalfArgs h, int n, hipStream_t s) {
+    int st;
+    if ((st = launch_ens_draw(e, n, s)) != ALABI_OK) return st;
+    const int n0 = h.n0, n1 = e->W - n0;
+    for (int t = 0; t < n; ++t) {
+        const size_t off = (size_t)t * e->W;
+        h.order = e->order + off; h.u_z = e->u_z + off; h.partner = e->partner + off; h.u_acc = e->u_acc + off;
+        h.local_t = t; h.part_begin = 0;
+        h.split = 0;
+        if ((st = launch_ens_half_args(e, h, n0, s)) != ALABI_OK) return st;
+        h.split = 1;
+        if ((st = launch_ens_half_args(e, h, n1, s)) != ALABI_OK) return st;
+    }
+    return launch_ens_advance(e, n, s);
+}
+
+int alabi_ens_run(alabi_ens* e, double* coords, double* logp, long long step0, long long nsteps, int thin_by,
+                  double a, double* chain, double* chain_logp, long long* n_accept, void* stream) {
+    if (!e || !coords || !logp || nsteps < 0 || thin_by < 1 || !(a > 1.0)) return ALABI_BAD_ARGUMENT;
+    if (!e->gp->computed || !e->gp->has_alpha) return ALABI_NOT_COMPUTED;
+    if (nsteps == 0) return ALABI_OK;
+    hipStream_t s = as_stream(stream);
+    int st;
+    if ((st = set_run_state(e, step0, 0, s)) != ALABI_OK) return st;
+    HalfArgs h = base_args(e, coords, logp, a);
+    h.chain = chain; h.chain_logp = chain_logp; h.n_accept = n_accept; h.thin_by = thin_by;
+
+    const char* env = getenv("ALABI_ENS_GRAPH");
+    const bool want_graph = (s != nullptr) && !(env && env[0] == '0');
+    int gsteps = e->chunk_cap < 256 ? e->chunk_cap : 256;
+    if (const char* gs = getenv("ALABI_ENS_GRAPH_STEPS")) {
+        int v = atoi(gs);
+        if (v > 0 && v <= e->chunk_cap) gsteps = v;
+    }
+    long long remaining = nsteps;
+    if (want_graph && remaining >= 2LL * gsteps) {
+        alabi_ens::GraphKey key{coords, logp, chain, chain_logp, n_accept, thin_by, gsteps, a, e->gp->gen};
+        const bool same = e->graph_exec && memcmp(&key, &e->graph_key, sizeof(key)) == 0;
+        if (!same) {
+            if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            ALABI_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            st = enqueue_chunk(e, h, gsteps, s);
+            hipError_t ce = hipStreamEndCapture(s, &graph);
+            if (st != ALABI_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+            if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture", __FILE__, __LINE__);
+            hipError_t ie = hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) { e->graph_exec = nullptr; return hip_fail(ie, "hipGraphInstantiate", __FILE__, __LINE__); }
+            memset(&e->graph_key, 0, sizeof(e->graph_key));
+            e->graph_key = key;
+            e->graph_steps = gsteps;
+        }
+        while (remaining >= gsteps) {
+            ALABI_HIP_CHECK(hipGraphLaunch(e->graph_exec, s));
+            remaining -= gsteps;
+        }
+    }
+    while (remaining > 0) {
+        const int n = (int)(remaining < e->chunk_cap ? remaining : e->chunk_cap);
+        if ((st = enqueue_chunk(e, h, n, s)) != ALABI_OK) return st;
+        remaining -= n;
+    }
+    return ALABI_OK;
+}
+
+int alabi_ens_draw(alabi_ens* e, long long step0, int nsteps, void* stream) {
+    if (!e || nsteps <= 0 || nsteps > e->chunk_cap) return ALABI_BAD_ARGUMENT;
+    hipStream_t s = as_stream(stream);
+    int st;
+    if ((st = set_run_state(e, step0, 0, s)) != ALABI_OK) return st;
+    e->drawn_step0 = step0; e->drawn_n = nsteps;
+    return launch_ens_draw(e, nsteps, s);
+}
+
+int alabi_ens_half_step(alabi_ens* e, double* coords, double* logp, int t, int split, int part_begin, int part_end,
+                        double a, long long* n_accept, void* stream) {
+    if (!e || !coords || !logp || t < 0 || t >= e->drawn_n || (split != 0 && split != 1) || !(a > 1.0))
+        return ALABI_BAD_ARGUMENT;
+    if (!e->gp->computed || !e->gp->has_alpha) return ALABI_NOT_COMPUTED;
+    HalfArgs h = base_args(e, coords, logp, a);
+    const int nS = split == 0 ? h.n0 : e->W - h.n0;
+    if (part_begin < 0 || part_end > nS || part_begin > part_end) return ALABI_BAD_ARGUMENT;
+    const size_t off = (size_t)t * e->W;
+    h.order = e->order + off; h.u_z = e->u_z + off; h.partner = e->partner + off; h.u_acc = e->u_acc + off;
+    h.local_t = t; h.split = split; h.part_begin = part_begin; h.n_accept = n_accept;
+    return launch_ens_half_args(e, h, part_end - part_begin, as_stream(stream));
+}
+
+int alabi_ens_step_lists(alabi_ens* e, int t, int* order_out, int* n0, void* stream) {
+    if (!e || t < 0 || t >= e->drawn_n || !order_out || !n0) return ALABI_BAD_ARGUMENT;
+    ALABI_HIP_CHECK(hipMemcpyAsync(order_out, e->order + (size_t)t * e->W, (size_t)e->W * sizeof(int),
+                                   hipMemcpyDeviceToDevice, as_stream(stream)));
+    *n0 = (e->W + 1) / 2;
+    return ALABI_OK;
+}
+
+int alabi_ens_step_with_randoms(alabi_ens* e, double* coords, double* logp, const int* order, int n0,
+                                const double* u_z, const int* partner, const double* u_acc, double a,
+                                long long* n_accept, void* stream) {
+    if (!e || !coords || !logp || !order || !u_z || !partner || !u_acc || n0 < 0 || n0 > e->W || !(a > 1.0))
+        return ALABI_BAD_ARGUMENT;
+    if (!e->gp->computed || !e->gp->has_alpha) return ALABI_NOT_COMPUTED;
+    hipStream_t s = as_stream(stream);
+    HalfArgs h = base_args(e, coords, logp, a);
+    h.order = order; h.n0 = n0; h.u_z = u_z; h.partner = partner; h.u_acc = u_acc; h.n_accept = n_accept;
+    h.local_t = 0; h.part_begin = 0;
+    int st;
+    h.split = 0;
+    if ((st = launch_ens_half_args(e, h, n0, s)) != ALABI_OK) return st;
+    h.split = 1;
+    return launch_ens_half_args(e, h, e->W - n0, s);
+}
+
+int alabi_ens_export_draws(alabi_ens* e, long long step, int* order, int* n0, double* u_z, int* partner,
+                           double* u_acc, void* stream) {
+    if (!e || !order || !n0 || !u_z || !partner || !u_acc) return ALABI_BAD_ARGUMENT;
+    hipStream_t s = as_stream(stream);
+    int st;
+    if ((st = alabi_ens_draw(e, step, 1, stream)) != ALABI_OK) return st;
+    const size_t W = e->W;
+    ALABI_HIP_CHECK(hipMemcpyAsync(order, e->order, W * sizeof(int), hipMemcpyDeviceToDevice, s));
+    ALABI_HIP_CHECK(hipMemcpyAsync(partner, e->partner, W * sizeof(int), hipMemcpyDeviceToDevice, s));
+    ALABI_HIP_CHECK(hipMemcpyAsync(u_z, e->u_z, W * sizeof(double), hipMemcpyDeviceToDevice, s));
+    ALABI_HIP_CHECK(hipMemcpyAsync(u_acc, e->u_acc, W * sizeof(double), hipMemcpyDeviceToDevice, s));
+    *n0 = (e->W + 1) / 2;
+    return ALABI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// Device helpers shared by the predict and ensemble kernels (gfx950, wave64).
+#pragma once
+#include "common.hpp"
+
+namespace alabi {
+
+// Compile-time dimension buckets: a GP of dimension d runs the instantiation for the
+// smallest bucket >= d; Xt rows beyond d are zero and so contribute nothing to r^2.
+__host__ __device__ inline int dim_bucket(int d) {
+    const int b[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64};
+    for (int i = 0; i < 15; ++i)
+        if (d <= b[i]) return b[i];
+    return -1;
+}
+
+#define ALABI_DISPATCH_DIM(DB, ...)                                   \
+    switch (DB) {                                                     \
+        case 1: { constexpr int D = 1; __VA_ARGS__; } break;          \
+        case 2: { constexpr int D = 2; __VA_ARGS__; } break;          \
+        case 3: { constexpr int D = 3; __VA_ARGS__; } break;          \
+        case 4: { constexpr int D = 4; __VA_ARGS__; } break;          \
+        case 5: { constexpr int D = 5; __VA_ARGS__; } break;          \
+        case 6: { constexpr int D = 6; __VA_ARGS__; } break;          \
+        case 8: { constexpr int D = 8; __VA_ARGS__; } break;          \
+        case 10: { constexpr int D = 10; __VA_ARGS__; } break;        \
+        case 12: { constexpr int D = 12; __VA_ARGS__; } break;        \
+        case 16: { constexpr int D = 16; __VA_ARGS__; } break;        \
+        case 20: { constexpr int D = 20; __VA_ARGS__; } break;        \
+        case 24: { constexpr int D = 24; __VA_ARGS__; } break;        \
+        case 32: { constexpr int D = 32; __VA_ARGS__; } break;        \
+        case 48: { constexpr int D = 48; __VA_ARGS__; } break;        \
+        case 64: { constexpr int D = 64; __VA_ARGS__; } break;        \
+        default: return ALABI_BAD_ARGUMENT;                           \
+    }
+
+// Sum over the 64 lanes of a wavefront (result valid in every lane).
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum over a 256-thread workgroup in a fixed order; `scratch` is >= 4 doubles of LDS.
+// Every thread returns the total.
+__device__ inline double block_sum_256(double v, double* scratch) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();  // scratch may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
+// sum_n alpha[n] * exp(-0.5 * |Xt[:,n] - q|^2) over all (padded) training points, one
+// query per workgroup: lanes run along n (coalesced SoA loads), then a block reduction.
+// q holds the query already multiplied by inv_len; padded points carry alpha = 0.
+template <int D>
+__device__ inline double gp_kernel_dot_block(const double* __restrict__ Xt, const double* __restrict__ alpha,
+                                             int Npad, const double* q_lds, double* scratch) {
+    double q[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[k] = q_lds[k];
+    double acc = 0.0;
+    for (int n = threadIdx.x; n < Npad; n += 256) {
+        double r2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double df = Xt[(size_t)k * Npad + n] - q[k];
+            r2 = fma(df, df, r2);
+        }
+        acc = fma(alpha[n], exp(-0.5 * r2), acc);
+    }
+    return block_sum_256(acc, scratch);
+}
+
+}  // namespace alabi

@@ -1,0 +1,371 @@
+"""HipGP: the george.GP object protocol that alabi touches, backed by libalabi_hip.so.
+
+Mirrors (member for member) what the reference calls on ``george.GP`` -- SURVEY.md
+section 8(b) seam #1: construction with ``kernel = var(y) * ExpSquaredKernel(metric, ndim)``,
+``mean=``, ``white_noise=`` (alabi/core.py:1141, alabi/gp_utils.py:230-233); ``compute``
+(core.py:1158); ``predict`` (core.py:85, :1601); ``log_likelihood`` /
+``grad_log_likelihood`` (core.py:1248, :1261); the parameter-vector protocol
+(core.py:705-733, :1050); ``kernel.get_value`` (utility.py:549); ``solver.get_inverse``
+(utility.py:610); private ``_x``, ``_y``, ``_alpha`` (utility.py:577); deepcopy / pickle.
+
+All arithmetic runs in the HIP library on the current CUDA(HIP) device; this class only
+moves arrays and keeps the hyper-parameter vector.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ["HipGP"]
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise RuntimeError("alabi_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback for the GP hot path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_dev(a, ndim=None):
+    if isinstance(a, torch.Tensor):
+        t = a.to(device=_dev(), dtype=torch.float64)
+    else:
+        t = torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float64)), device=_dev())
+    if ndim == 2 and t.dim() == 1:
+        t = t.reshape(1, -1)
+    return t.contiguous()
+
+
+class _KernelView:
+    """gp.kernel: get_value(x1, x2) without white noise, parameter names (utility.py:549, gp_utils.py:333)."""
+
+    def __init__(self, gp):
+        self._gp = gp
+
+    @property
+    def ndim(self):
+        return self._gp.ndim
+
+    def get_parameter_names(self, include_frozen=False):
+        return tuple(["k1:log_constant"] + [f"k2:metric:log_M_{i}_{i}" for i in range(self._gp.ndim)])
+
+    def get_parameter_vector(self, include_frozen=False):
+        return np.concatenate([[self._gp.log_constant], self._gp.log_M])
+
+    def get_value(self, x1, x2=None, diag=False):
+        gp = self._gp
+        a = _to_dev(x1, 2)
+        if diag:
+            return np.full(a.shape[0], np.exp(gp.log_constant))
+        b = a if x2 is None else _to_dev(x2, 2)
+        out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=a.device)
+        st = _lib.lib().alabi_kernel_matrix(_lib.ptr(a), a.shape[0], _lib.ptr(b), b.shape[0], gp.ndim,
+                                            float(gp.log_constant), _lib.host_doubles(gp.log_M), _lib.ptr(out),
+                                            _lib.current_stream())
+        _lib.check(st, "alabi_kernel_matrix")
+        return out.cpu().numpy()
+
+
+class _SolverView:
+    """gp.solver: log_determinant, get_inverse (utility.py:610), apply_inverse."""
+
+    def __init__(self, gp):
+        self._gp = gp
+
+    @property
+    def log_determinant(self):
+        return self._gp._logdet()
+
+    def get_factor(self):
+        gp = self._gp
+        gp._require_computed()
+        n = gp._n
+        out = torch.empty((n, n), dtype=torch.float64, device=_dev())
+        _lib.check(_lib.lib().alabi_gp_get_factor(gp._handle, _lib.ptr(out), _lib.current_stream()), "alabi_gp_get_factor")
+        return out
+
+    def get_inverse(self):
+        # K^-1 = L^-T L^-1 from the native factor (interim: the two triangular solves against the
+        # identity use torch; only the finite-difference gradient helpers of the reference need it)
+        L = self.get_factor()
+        eye = torch.eye(L.shape[0], dtype=torch.float64, device=L.device)
+        return torch.cholesky_solve(eye, L).cpu().numpy()
+
+
+class HipGP:
+    def __init__(self, ndim, mean=0.0, white_noise=-12.0, log_constant=0.0, log_M=None,
+                 fit_mean=True, fit_white_noise=True):
+        self.ndim = int(ndim)
+        if not (1 <= self.ndim <= _lib.MAX_DIM):
+            raise ValueError(f"ndim must be in [1, {_lib.MAX_DIM}]")
+        self.mean_value = float(mean)
+        self.white_noise_value = float(white_noise)
+        self.log_constant = float(log_constant)
+        self.log_M = np.zeros(self.ndim) if log_M is None else np.array(log_M, dtype=np.float64).ravel().copy()
+        if self.log_M.size != self.ndim:
+            raise ValueError("log_M must have ndim entries")
+        self.fit_mean = bool(fit_mean)
+        self.fit_white_noise = bool(fit_white_noise)
+        self.kernel = _KernelView(self)
+        self.solver = _SolverView(self)
+        self._x = None          # numpy [N,d] (host copy: pickling, protocol)
+        self._y = None          # numpy [N]
+        self._alpha_host = None
+        self._handle = None
+        self._cap = 0
+        self._n = 0
+        self._x_dev = None
+        self.computed = False
+        self.dirty = True
+        self._y_set = False
+
+    # ------------------------------------------------------------------ handle lifetime
+    def _ensure_handle(self, n):
+        if self._handle is not None and n <= self._cap:
+            return
+        self._release()
+        cap = max(int(n * 1.25) + 64, 128)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().alabi_gp_create(cap, self.ndim, C.byref(h)), "alabi_gp_create")
+        self._handle = h
+        self._cap = cap
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            try:
+                _lib.lib().alabi_gp_destroy(self._handle)
+            except Exception:
+                pass
+        self._handle = None
+        self._cap = 0
+
+    def __del__(self):
+        self._release()
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        for k in ("_handle", "_x_dev", "kernel", "solver"):
+            st[k] = None
+        st["_cap"] = 0
+        st["_was_computed"] = self.computed
+        st["computed"] = False
+        st["_y_set"] = False
+        st["dirty"] = True
+        return st
+
+    def __setstate__(self, st):
+        was = st.pop("_was_computed", False)
+        self.__dict__.update(st)
+        self.kernel = _KernelView(self)
+        self.solver = _SolverView(self)
+        self._restore = bool(was and self._x is not None)
+
+    def _require_computed(self):
+        if getattr(self, "_restore", False):
+            self._restore = False
+            self.compute(self._x)
+        if not self.computed or self.dirty:
+            if self._x is None:
+                raise RuntimeError("You need to compute the model first")
+            self.compute(self._x)
+
+    # ------------------------------------------------------------ parameter-vector protocol
+    def get_parameter_names(self, include_frozen=False):
+        names = []
+        if self.fit_mean or include_frozen:
+            names.append("mean:value")
+        if self.fit_white_noise or include_frozen:
+            names.append("white_noise:value")
+        names.append("kernel:k1:log_constant")
+        names += [f"kernel:k2:metric:log_M_{i}_{i}" for i in range(self.ndim)]
+        return tuple(names)
+
+    def get_parameter_vector(self, include_frozen=False):
+        v = []
+        if self.fit_mean or include_frozen:
+            v.append(self.mean_value)
+        if self.fit_white_noise or include_frozen:
+            v.append(self.white_noise_value)
+        v.append(self.log_constant)
+        v.extend(self.log_M.tolist())
+        return np.array(v, dtype=np.float64)
+
+    def get_parameter_dict(self, include_frozen=False):
+        return OrderedDict(zip(self.get_parameter_names(include_frozen), self.get_parameter_vector(include_frozen)))
+
+    def set_parameter_vector(self, vector, include_frozen=False):
+        p = np.asarray(vector, dtype=np.float64).ravel()
+        n_expected = len(self.get_parameter_names(include_frozen))
+        if p.size != n_expected:
+            raise ValueError(f"dimension mismatch: expected {n_expected} parameters, got {p.size}")
+        i = 0
+        if self.fit_mean or include_frozen:
+            self.mean_value = float(p[i]); i += 1
+        if self.fit_white_noise or include_frozen:
+            self.white_noise_value = float(p[i]); i += 1
+        self.log_constant = float(p[i]); i += 1
+        self.log_M = p[i:i + self.ndim].copy()
+        self.dirty = True
+        self._y_set = False
+        self._alpha_host = None
+
+    def __len__(self):
+        return len(self.get_parameter_names())
+
+    # ------------------------------------------------------------------ compute / predict
+    def _push_hyper(self):
+        st = _lib.lib().alabi_gp_set_hyper(self._handle, self.mean_value, self.white_noise_value, self.log_constant,
+                                           _lib.host_doubles(self.log_M))
+        _lib.check(st, "alabi_gp_set_hyper")
+
+    def compute(self, x, yerr=0.0, quiet=False):
+        """Assemble K and factorise it (george GP.compute; reference core.py:1158)."""
+        xd = _to_dev(x, 2)
+        if xd.shape[1] != self.ndim:
+            raise ValueError(f"x has {xd.shape[1]} columns, GP has ndim={self.ndim}")
+        n = int(xd.shape[0])
+        self._ensure_handle(n)
+        self._push_hyper()
+        self._x_dev = xd
+        self._x = x if (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.ndim == 2) else xd.cpu().numpy()
+        self._n = n
+        self._restore = False
+        st = _lib.lib().alabi_gp_compute(self._handle, _lib.ptr(xd), n, _lib.current_stream())
+        self._y_set = False
+        self._alpha_host = None
+        if st == _lib.NOT_PD:
+            self.computed = False
+            piv = C.c_int(0)
+            _lib.lib().alabi_gp_last_pivot(self._handle, C.byref(piv))
+            if quiet:
+                return False
+            raise np.linalg.LinAlgError(f"{piv.value}-th leading minor of the array is not positive definite")
+        _lib.check(st, "alabi_gp_compute")
+        self.computed = True
+        self.dirty = False
+        return True
+
+    def recompute(self, quiet=False, **kw):
+        if self._x is None:
+            raise RuntimeError("You need to compute the model first")
+        if self.dirty or not self.computed or getattr(self, "_restore", False):
+            try:
+                ok = self.compute(self._x_dev if self._x_dev is not None else self._x, quiet=quiet)
+            except np.linalg.LinAlgError:
+                if quiet:
+                    return False
+                raise
+            return bool(ok)
+        return True
+
+    def _set_y(self, y):
+        if isinstance(y, torch.Tensor):
+            yd = _to_dev(y).reshape(-1)
+            same = False
+            yh = None
+        else:
+            yh = np.asarray(y, dtype=np.float64).ravel()
+            same = self._y_set and self._y is not None and np.array_equal(yh, self._y)
+            yd = None
+        if same:
+            return
+        if yd is None:
+            yd = _to_dev(yh)
+        if yd.numel() != self._n:
+            raise ValueError(f"dimension mismatch: y has {yd.numel()} entries, GP was computed on {self._n} points")
+        _lib.check(_lib.lib().alabi_gp_set_y(self._handle, _lib.ptr(yd), _lib.current_stream()), "alabi_gp_set_y")
+        self._y = yh if yh is not None else yd.cpu().numpy()
+        self._y_set = True
+        self._alpha_host = None
+
+    def predict_device(self, y, t, return_var=False):
+        """predict() with device tensors in and out (no host round trip)."""
+        self._require_computed()
+        self._set_y(y)
+        td = _to_dev(t, 2)
+        if td.shape[1] != self.ndim:
+            raise ValueError(f"t has {td.shape[1]} columns, GP has ndim={self.ndim}")
+        m = int(td.shape[0])
+        mu = torch.empty(m, dtype=torch.float64, device=td.device)
+        var = torch.empty(m, dtype=torch.float64, device=td.device) if return_var else None
+        st = _lib.lib().alabi_gp_predict(self._handle, _lib.ptr(td), m, _lib.ptr(mu), _lib.ptr(var), _lib.current_stream())
+        _lib.check(st, "alabi_gp_predict")
+        return (mu, var) if return_var else mu
+
+    def predict(self, y, t, return_cov=True, return_var=False, cache=True, kernel=None):
+        """george GP.predict (core.py:85, :95, :1441, :1601).  return_var wins over return_cov."""
+        if return_var:
+            mu, var = self.predict_device(y, t, return_var=True)
+            return mu.cpu().numpy(), var.cpu().numpy()
+        if return_cov:
+            raise NotImplementedError("HipGP.predict(return_cov=True) is not on alabi's path; "
+                                      "pass return_cov=False or return_var=True")
+        return self.predict_device(y, t, return_var=False).cpu().numpy()
+
+    # ----------------------------------------------------------------------- likelihood
+    def _logdet(self):
+        self._require_computed()
+        out = C.c_double(0.0)
+        _lib.check(_lib.lib().alabi_gp_logdet(self._handle, C.byref(out), _lib.current_stream()), "alabi_gp_logdet")
+        return out.value
+
+    def log_likelihood(self, y, quiet=False):
+        """george GP.log_likelihood (core.py:1248, gp_utils.py:139)."""
+        try:
+            ok = self.recompute(quiet=quiet)
+        except np.linalg.LinAlgError:
+            if quiet:
+                return -np.inf
+            raise
+        if not ok:
+            return -np.inf
+        self._set_y(y)
+        out = C.c_double(0.0)
+        _lib.check(_lib.lib().alabi_gp_nll(self._handle, C.byref(out), _lib.current_stream()), "alabi_gp_nll")
+        ll = -out.value
+        return ll if np.isfinite(ll) else -np.inf
+
+    def nll(self, y):
+        return -self.log_likelihood(y, quiet=True)
+
+    def grad_log_likelihood(self, y, quiet=False, h=1e-5):
+        """d logL / d p by central differences of the native likelihood (2 x len(p) factorisations).
+
+        INTERIM: george's analytic 0.5 tr((aa^T - K^-1) dK/dp) needs a
+        K^-1 and dK/dp contraction kernel that is not written yet.
+        """
+        p0 = self.get_parameter_vector()
+        g = np.zeros_like(p0)
+        for i in range(p0.size):
+            pp = p0.copy(); pp[i] += h
+            self.set_parameter_vector(pp)
+            fp = self.log_likelihood(y, quiet=True)
+            pm = p0.copy(); pm[i] -= h
+            self.set_parameter_vector(pm)
+            fm = self.log_likelihood(y, quiet=True)
+            g[i] = (fp - fm) / (2.0 * h)
+        self.set_parameter_vector(p0)
+        self.recompute(quiet=True)
+        return g
+
+    # -------------------------------------------------------------------- private members
+    @property
+    def _alpha(self):
+        """alpha = K^-1 (y - mean) as a host array (reference reads gp._alpha at utility.py:577)."""
+        if self._alpha_host is None:
+            if not (self.computed and self._y_set):
+                return None
+            out = torch.empty(self._n, dtype=torch.float64, device=_dev())
+            _lib.check(_lib.lib().alabi_gp_get_alpha(self._handle, _lib.ptr(out), _lib.current_stream()), "alabi_gp_get_alpha")
+            self._alpha_host = out.cpu().numpy()
+        return self._alpha_host
+
+    @property
+    def handle(self):
+        self._require_computed()
+        return self._handle

@@ -1,0 +1,258 @@
+"""Host-side mirror of the parts of alabi/utility.py that sit on the hot path's boundary.
+
+* scalers ``no_scaler`` / ``log_scaler`` / ``nlog_scaler`` (alabi/utility.py:45-72),
+* ``prior_sampler`` (utility.py:79-199; skopt is replaced by NumPy / scipy.stats.qmc),
+* ``lnprior_uniform`` / ``prior_transform_uniform`` (utility.py:218-367), ``logsubexp`` (:489-504),
+* the acquisition functions ``bape_utility`` / ``agp_utility`` / ``jones_utility`` with the
+  reference's one-point signature ``f(theta, predict_gp, bounds)`` (utility.py:629-946),
+* ``minimize_objective`` multistart (utility.py:969-1163),
+* and the batched device form ``utility_scan`` (HIP: predict-variance + epilogue + arg-min),
+  which is what ``SurrogateModel.find_next_point`` uses by default.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+import warnings
+
+import numpy as np
+import torch
+from scipy.optimize import minimize
+from scipy.stats import norm, qmc
+from sklearn.preprocessing import FunctionTransformer
+
+from . import _lib
+
+__all__ = ["agp_utility", "bape_utility", "jones_utility", "assign_utility", "minimize_objective",
+           "prior_sampler", "lnprior_uniform", "prior_transform_uniform", "logsubexp",
+           "NewFunctionTransformer", "nlog_scaler", "log_scaler", "no_scaler",
+           "utility_scan", "utility_eval_device"]
+
+
+class NewFunctionTransformer(FunctionTransformer):
+    """FunctionTransformer carrying a printable name (utility.py:45-58)."""
+
+    def __init__(self, name="scaler", func=None, inverse_func=None, *, validate=False, accept_sparse=False,
+                 check_inverse=True, feature_names_out=None, kw_args=None, inv_kw_args=None):
+        super().__init__(func=func, inverse_func=inverse_func, validate=validate, accept_sparse=accept_sparse,
+                         check_inverse=check_inverse, feature_names_out=feature_names_out, kw_args=kw_args,
+                         inv_kw_args=inv_kw_args)
+        self.name = name
+
+    def __str__(self):
+        return self.name
+
+    __repr__ = __str__
+
+
+def _nlog(x): return np.log10(-x)
+def _nlog_inv(x): return -10 ** x
+def _log(x): return np.log10(x)
+def _log_inv(x): return 10 ** x
+def _ident(x): return x
+
+
+nlog_scaler = NewFunctionTransformer(name="nlog_scaler", func=_nlog, inverse_func=_nlog_inv)
+log_scaler = NewFunctionTransformer(name="log_scaler", func=_log, inverse_func=_log_inv)
+no_scaler = NewFunctionTransformer(name="no_scaler", func=_ident, inverse_func=_ident)
+
+
+def prior_sampler(bounds=None, nsample=1, sampler="uniform", random_state=None):
+    """Samples in the box ``bounds`` -> array (nsample, ndim)  (utility.py:79-199).
+
+    uniform: NumPy RandomState (time-seeded when random_state is None, as the reference);
+    sobol / lhs / halton: scipy.stats.qmc (the reference used skopt, not installed here).
+    """
+    b = np.asarray(bounds, dtype=np.float64)
+    ndim = len(b)
+    nsample = int(nsample)
+    if random_state is None:
+        random_state = int(time.time() * 1000000) % (2 ** 32)
+    lo, span = b[:, 0], b[:, 1] - b[:, 0]
+    if sampler == "uniform":
+        rs = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+        u = rs.rand(nsample, ndim)
+    elif sampler == "sobol":
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            u = qmc.Sobol(d=ndim, scramble=False).random(nsample + 1)[1:]
+    elif sampler == "lhs":
+        u = qmc.LatinHypercube(d=ndim, seed=random_state if not isinstance(random_state, np.random.RandomState) else None).random(nsample)
+    elif sampler == "halton":
+        u = qmc.Halton(d=ndim, scramble=False).random(nsample + 1)[1:]
+    elif sampler == "grid":
+        per = max(int(np.floor(nsample ** (1.0 / ndim))), 1)
+        axes = [np.linspace(0.0, 1.0, per) for _ in range(ndim)]
+        u = np.stack([m.ravel() for m in np.meshgrid(*axes, indexing="ij")], axis=1)[:nsample]
+    else:
+        raise ValueError(f"Sampler method '{sampler}' not implemented. Valid options for 'sampler' are: "
+                         "uniform, sobol, lhs, halton, grid.")
+    return lo + span * u
+
+
+def lnprior_uniform(x, bounds):
+    """0.0 strictly inside the open box, -inf otherwise (utility.py:218-275)."""
+    b = np.asarray(bounds, dtype=np.float64)
+    ndim = len(b)
+    x = np.array([x]).ravel() if ndim == 1 else np.array(x).squeeze()
+    inside = True
+    for i in range(ndim):
+        inside = inside and bool((x[i] > b[i][0]) and (x[i] < b[i][1]))
+    return 0.0 if inside else -np.inf
+
+
+def prior_transform_uniform(theta, bounds):
+    """Unit hypercube -> box (utility.py:278-367)."""
+    theta = np.asarray(theta, dtype=float)
+    b = np.asarray(bounds, dtype=float)
+    if theta.ndim not in (1, 2):
+        raise ValueError(f"theta must be 1D or 2D array, got {theta.ndim}D array with shape {theta.shape}")
+    if theta.shape[-1] != len(b):
+        raise ValueError(f"Bounds length ({len(b)}) must match theta dimensions ({theta.shape[-1]})")
+    return (b[:, 1] - b[:, 0]) * theta + b[:, 0]
+
+
+def logsubexp(x1, x2):
+    """log(exp(x1) - exp(x2)), -inf if x1 <= x2 (utility.py:489-504)."""
+    if x1 <= x2:
+        return -np.inf
+    return x1 + np.log(1.0 - np.exp(x2 - x1))
+
+
+def _mu_var(predict_gp, theta):
+    mu, var = predict_gp(np.asarray(theta, dtype=np.float64).reshape(1, -1))
+    return float(np.asarray(mu).ravel()[0]), float(np.asarray(var).ravel()[0])
+
+
+def bape_utility(theta, predict_gp, bounds):
+    """-[2 mu + var + log(exp(var) - 1)]; +inf outside the box (utility.py:729-810)."""
+    theta = np.asarray(theta).flatten()
+    if not np.isfinite(lnprior_uniform(theta, bounds)):
+        return np.inf
+    mu, var = _mu_var(predict_gp, theta)
+    return float(-((2.0 * mu + var) + logsubexp(var, 0.0)))
+
+
+def agp_utility(theta, predict_gp, bounds):
+    """-[mu + 0.5 log(2 pi e var)]; +inf outside the box (utility.py:629-701)."""
+    theta = np.asarray(theta)
+    if not np.isfinite(lnprior_uniform(theta, bounds)):
+        return np.inf
+    mu, var = _mu_var(predict_gp, theta)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return float(-(mu + 0.5 * np.log(2.0 * np.pi * np.e * var)))
+
+
+def jones_utility(theta, predict_gp, bounds, y_best, zeta=0.01):
+    """Negative expected improvement; 0.0 when the predictive std is not positive (utility.py:853-946)."""
+    theta = np.asarray(theta)
+    if not np.isfinite(lnprior_uniform(theta, bounds)):
+        return np.inf
+    mu, var = _mu_var(predict_gp, theta)
+    with np.errstate(invalid="ignore"):
+        std = np.sqrt(var)
+    if not (std > 0):
+        return 0.0
+    z = (mu - y_best - zeta) / std
+    return float(-((mu - y_best - zeta) * norm.cdf(z) + std * norm.pdf(z)))
+
+
+def assign_utility(algorithm):
+    """name -> (utility, grad_utility)  (utility.py:949-966).  Analytic gradients are not provided
+    (SURVEY.md section 8(f) #4): optimisers fall back to scipy's finite differences."""
+    table = {"bape": bape_utility, "agp": agp_utility, "jones": jones_utility}
+    if algorithm not in table:
+        print(f"ERROR: Unknown utility function: {algorithm}. Defaulting to BAPE.")
+        return bape_utility, None
+    return table[algorithm], None
+
+
+# ---- device batch forms ---------------------------------------------------------------------
+
+def utility_eval_device(algorithm, theta, bounds, mu, var, y_best=0.0):
+    """Epilogue only: u[M] from caller-supplied (mu, var) device tensors."""
+    from .gp import _to_dev
+    th = _to_dev(theta, 2)
+    mu = _to_dev(mu); var = _to_dev(var)
+    m, d = int(th.shape[0]), int(th.shape[1])
+    u = torch.empty(m, dtype=torch.float64, device=th.device)
+    b = np.ascontiguousarray(np.asarray(bounds, dtype=np.float64).reshape(d, 2))
+    st = _lib.lib().alabi_utility_eval(_lib.UTILITY_CODES[algorithm], _lib.ptr(th), m, d, _lib.host_doubles(b.ravel()),
+                                       float(y_best), _lib.ptr(mu), _lib.ptr(var), _lib.ptr(u), _lib.current_stream())
+    _lib.check(st, "alabi_utility_eval")
+    return u
+
+
+def utility_scan(gp, y, theta, bounds, algorithm="bape", y_best=0.0, return_all=False):
+    """Evaluate the acquisition function on M candidates on the GPU and return the arg-min.
+
+    Returns (theta_best[d] numpy, u_best, index) and, with return_all, also (u, mu, var) device tensors.
+    Non-finite utilities (outside the box, var <= 0 for bape, ...) never win, as in
+    utility.minimize_objective (utility.py:1149-1163).  index is -1 if no candidate is finite.
+    """
+    from .gp import _to_dev
+    th = _to_dev(theta, 2)
+    m, d = int(th.shape[0]), int(th.shape[1])
+    gp.predict_device(y, th[:1])  # makes sure K is factorised and alpha matches y
+    b = np.ascontiguousarray(np.asarray(bounds, dtype=np.float64).reshape(d, 2))
+    u = mu = var = None
+    if return_all:
+        u = torch.empty(m, dtype=torch.float64, device=th.device)
+        mu = torch.empty_like(u); var = torch.empty_like(u)
+    best_val = C.c_double(0.0)
+    best_idx = C.c_longlong(-1)
+    st = _lib.lib().alabi_utility_scan(gp.handle, _lib.UTILITY_CODES[algorithm], _lib.ptr(th), m,
+                                       _lib.host_doubles(b.ravel()), float(y_best), _lib.ptr(u), _lib.ptr(mu),
+                                       _lib.ptr(var), C.byref(best_val), C.byref(best_idx), _lib.current_stream())
+    _lib.check(st, "alabi_utility_scan")
+    idx = int(best_idx.value)
+    best_theta = th[idx].cpu().numpy() if idx >= 0 else np.full(d, np.nan)
+    out = (best_theta, float(best_val.value), idx)
+    return out + (u, mu, var) if return_all else out
+
+
+# ---- multistart local optimiser (reference semantics, one point per objective call) ----------
+
+def minimize_objective_single(idx, obj_fn, bounds, starting_point, method, options, grad_obj_fn=None):
+    res = minimize(fun=obj_fn, x0=np.array(starting_point).flatten(), jac=grad_obj_fn, bounds=bounds,
+                   method=method, options=options)
+    x_opt, f_opt = res.x, res.fun
+    if not (np.all(np.isfinite(x_opt)) and np.all(np.isfinite(f_opt))):
+        print("Warning: Acquisition function optimization infinite fail", x_opt, f_opt)
+        return np.nan, np.nan
+    if not np.isfinite(lnprior_uniform(x_opt, bounds)):
+        print("Warning: Acquisition function optimization prior fail", x_opt)
+        return np.nan, np.nan
+    if res.nit > 5:
+        return x_opt, f_opt
+    print(f"Warning: Aquisition function ran for {res.nit} iterations. Optimizer success: {res.success}")
+    return (np.nan, np.nan) if res.nit <= 1 else (x_opt, f_opt)
+
+
+def minimize_objective(obj_fn, bounds=None, nopt=1, method="l-bfgs-b", ps=None, options=None,
+                       grad_obj_fn=None, pool=None):
+    """Best of ``nopt`` local minimisations from random starts (utility.py:1030-1163)."""
+    warnings.filterwarnings("ignore", category=RuntimeWarning)
+    m = str(method).lower()
+    if options is None:
+        options = ({"maxiter": 100, "ftol": 1e-6, "gtol": 1e-5} if m == "l-bfgs-b"
+                   else {"maxiter": 200, "xatol": 1e-6, "fatol": 1e-6} if m == "nelder-mead" else {"maxiter": 100})
+    else:
+        options = dict(options)
+        for old, new in (("max_iter", "maxiter"), ("max_eval", "maxfev"), ("max_fun", "maxfun")):
+            if old in options:
+                options[new] = options.pop(old)
+    if m == "nelder-mead":
+        options["adaptive"] = True
+        grad_obj_fn = None
+    elif m == "l-bfgs-b":
+        options.setdefault("maxcor", 10)
+    starts = prior_sampler(bounds, nsample=nopt, sampler="lhs") if ps is None else ps(nsample=nopt)
+    starts = np.array([np.asarray(p).flatten() for p in starts])
+    results = [minimize_objective_single(i, obj_fn, bounds, starts[i], method, options, grad_obj_fn) for i in range(nopt)]
+    valid = [(t, o) for t, o in results if np.all(np.isfinite(t)) and np.isfinite(o)]
+    if not valid:
+        print(f"Warning: All {nopt} optimization attempts failed. Returning NaN.")
+        return np.nan, np.nan
+    k = int(np.argmin([o for _, o in valid]))
+    return valid[k]

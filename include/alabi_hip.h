@@ -1,0 +1,150 @@
+/*
+ * alabi_hip.h -- C ABI of libalabi_hip.so, the MI355X (gfx950) implementation of the
+ * GP-surrogate + ensemble-MCMC hot path of jbirky/alabi.
+ *
+ * The reference has no FFI: it reaches this arithmetic through the Python object
+ * protocols of two third-party packages (george.GP, emcee.EnsembleSampler).  Each entry
+ * point below names the reference call site (path:line under /root/reference) whose work
+ * it replaces; INTEGRATION.md shows the ctypes binding a maintainer adds on the alabi side.
+ *
+ * Conventions
+ *   - All array arguments are DEVICE pointers to float64 / int32 / int64 unless marked
+ *     "host".  They are owned by the caller (PyTorch-ROCm tensors' data_ptr()).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Work is
+ *     enqueued on it; only the calls documented as synchronising wait for it.
+ *   - Every call returns an int status; no exception crosses the boundary.
+ *   - A handle is not thread-safe; distinct handles are independent.
+ *   - Everything computes in IEEE fp64.
+ */
+#ifndef ALABI_HIP_H
+#define ALABI_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALABI_OK 0
+#define ALABI_NOT_POSITIVE_DEFINITE 1 /* Cholesky met a pivot <= 0 or NaN (see alabi_gp_last_pivot) */
+#define ALABI_BAD_ARGUMENT 2
+#define ALABI_HIP_ERROR 3
+#define ALABI_NOT_COMPUTED 4          /* predict / set_y before a successful compute */
+
+#define ALABI_UTILITY_BAPE 0
+#define ALABI_UTILITY_AGP 1
+#define ALABI_UTILITY_JONES 2
+
+#define ALABI_MAX_DIM 64
+
+typedef struct alabi_gp alabi_gp;
+typedef struct alabi_ens alabi_ens;
+
+/* Library / device --------------------------------------------------------------------- */
+int alabi_abi_version(void);
+const char* alabi_status_string(int status);
+const char* alabi_last_error(void);            /* text of the last HIP error on this thread */
+int alabi_device_info(int* n_cu, int* lds_bytes, char* arch /* >=64 bytes, host */);
+
+/* GP object: replaces george.GP(kernel=var(y)*ExpSquaredKernel(metric, ndim), mean=,
+ * white_noise=)  -- alabi/core.py:1000, :1141; alabi/gp_utils.py:230-233. ---------------- */
+int alabi_gp_create(int n_cap, int d, alabi_gp** out);
+int alabi_gp_destroy(alabi_gp* gp);
+
+/* gp.set_parameter_vector(p) -- alabi/core.py:705-733, :1157.  log_M is a host array[d];
+ * all three log_* values are natural logs (george convention). */
+int alabi_gp_set_hyper(alabi_gp* gp, double mean, double log_white_noise, double log_amp,
+                       const double* log_M);
+
+/* gp.compute(X) -- alabi/core.py:1158, :1430, :1577; gp_utils.py:243.  Assembles
+ * K = k(X,X) + exp(log_white_noise) I and factorises it (lower Cholesky).  X is [N,d]
+ * row-major on the device.  SYNCHRONISES the stream (it returns the factorisation status).
+ * Returns ALABI_NOT_POSITIVE_DEFINITE where LAPACK's potrf would report info > 0. */
+int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream);
+int alabi_gp_last_pivot(alabi_gp* gp, int* pivot /* host, 1-based like LAPACK info */);
+
+/* alpha = K^-1 (y - mean): george _compute_alpha inside gp.predict -- alabi/core.py:85. */
+int alabi_gp_set_y(alabi_gp* gp, const double* y, void* stream);
+
+/* gp.predict(y, Xs, return_var=) -- alabi/core.py:85, :95, :1441, :1486, :1601, :1812.
+ * Xs is [M,d] row-major; mu[M]; var[M] or NULL (mean only).  White noise is not added
+ * to var.  var may come out slightly negative from cancellation, as in the reference. */
+int alabi_gp_predict(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var,
+                     void* stream);
+
+/* solver.log_determinant and -gp.log_likelihood(y) -- alabi/core.py:1248; gp_utils.py:139.
+ * Both SYNCHRONISE the stream and write one host double. */
+int alabi_gp_logdet(alabi_gp* gp, double* out, void* stream);
+int alabi_gp_nll(alabi_gp* gp, double* out, void* stream);
+
+/* Inspection (tests, GP-protocol adapter: gp._alpha, utility.py:577; solver factor). */
+int alabi_gp_get_alpha(alabi_gp* gp, double* alpha_out /* [N] */, void* stream);
+int alabi_gp_get_factor(alabi_gp* gp, double* L_out /* [N,N] row-major, upper part zero */,
+                        void* stream);
+int alabi_gp_n(alabi_gp* gp, int* n /* host */);
+
+/* kernel.get_value(x1, x2) -- alabi/utility.py:549, :607.  K_out is [n1,n2] row-major,
+ * no white noise. */
+int alabi_kernel_matrix(const double* X1, int n1, const double* X2, int n2, int d,
+                        double log_amp, const double* log_M /* host [d] */, double* K_out,
+                        void* stream);
+
+/* Acquisition scan: utility.bape_utility / agp_utility / jones_utility evaluated on M
+ * candidates + the arg-min that utility.minimize_objective takes over restarts --
+ * alabi/utility.py:729-810, :629-701, :853-946, :1149-1163; alabi/core.py:1601-1621.
+ * Xs [M,d]; bounds host [d,2]; u [M] or NULL; best_val / best_idx are HOST outputs
+ * (SYNCHRONISES).  Candidates outside the open box get +inf. */
+int alabi_utility_scan(alabi_gp* gp, int algo, const double* Xs, long long M,
+                       const double* bounds, double y_best, double* u, double* mu_out,
+                       double* var_out, double* best_val, long long* best_idx, void* stream);
+/* The epilogue alone on caller-supplied (mu, var): used by the parity tests. */
+int alabi_utility_eval(int algo, const double* Xs, long long M, int d, const double* bounds,
+                       double y_best, const double* mu, const double* var, double* u,
+                       void* stream);
+
+/* Ensemble sampler: replaces emcee.EnsembleSampler(W, d, sm.lnprob).run_mcmc(p0, nsteps)
+ * with the StretchMove -- alabi/core.py:2319-2325, lnprob = surrogate mean + box prior
+ * (alabi/core.py:2073-2100, utility.py:218-275).  Walkers [first_walker, first_walker +
+ * n_local) are the ones THIS rank proposes for (multi-GPU sharding); a single-GPU run
+ * passes 0, W.  bounds is a host array [d,2] in the GP's (scaled) coordinates. */
+int alabi_ens_create(alabi_gp* gp, int W, int d, const double* bounds,
+                     unsigned long long seed, alabi_ens** out);
+int alabi_ens_destroy(alabi_ens* ens);
+
+/* log-probability of an ensemble of points (surrogate mean + box prior). */
+int alabi_ens_lnprob(alabi_ens* ens, const double* coords /* [W,d] */, double* logp /* [W] */,
+                     void* stream);
+
+/* Run nsteps full stretch-move steps on one GPU.  coords [W,d] and logp [W] are updated in
+ * place; chain [nsteps/thin_by, W, d] and chain_logp [nsteps/thin_by, W] receive every
+ * thin_by-th state (either may be NULL); n_accept [W] int64 is ADDED to.  step0 is the
+ * global index of the first step (counter-based RNG: draws depend on (seed, step, walker)
+ * only).  Enqueues on `stream`; does not synchronise. */
+int alabi_ens_run(alabi_ens* ens, double* coords, double* logp, long long step0,
+                  long long nsteps, int thin_by, double a, double* chain, double* chain_logp,
+                  long long* n_accept, void* stream);
+
+/* Multi-GPU building blocks (alabi_amd/dist.py drives them around an RCCL all-gather):
+ * draw the randoms of steps [step0, step0+nsteps) into the handle, then apply one HALF
+ * step (split 0 or 1 of local step `t`) to the walkers whose position in that half's list
+ * lies in [part_begin, part_end). */
+int alabi_ens_draw(alabi_ens* ens, long long step0, int nsteps, void* stream);
+int alabi_ens_half_step(alabi_ens* ens, double* coords, double* logp, int t, int split,
+                        int part_begin, int part_end, double a, long long* n_accept,
+                        void* stream);
+/* copy of the walker lists of drawn local step t: order_out[W] int32 (device), n0 (host). */
+int alabi_ens_step_lists(alabi_ens* ens, int t, int* order_out, int* n0, void* stream);
+
+/* Test entry: one full step from caller-supplied draws keyed by walker id (bit-exact
+ * index-arithmetic fixtures).  order[W] int32 lists set 0 then set 1; partner[W] int32
+ * indexes the complementary list. */
+int alabi_ens_step_with_randoms(alabi_ens* ens, double* coords, double* logp,
+                                const int* order, int n0, const double* u_z,
+                                const int* partner, const double* u_acc, double a,
+                                long long* n_accept, void* stream);
+/* Test entry: the device's counter-based draws for one step, copied out. */
+int alabi_ens_export_draws(alabi_ens* ens, long long step, int* order /* [W] */, int* n0 /* host */,
+                           double* u_z, int* partner, double* u_acc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALABI_HIP_H */

@@ -1,0 +1,153 @@
+"""GPU parity of the ensemble sampler (through the C ABI) against oracle/stretch_oracle.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import torch
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    X, y, h = make_problem(500, 5, 31)
+    g = HipGP(5, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+    o = OracleGP(5, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X)
+    bounds = np.array([[-3.0, 3.0]] * 5)
+    return torch, g, o, y, bounds
+
+
+def _lnp(o, y, bounds):
+    from oracle.stretch_oracle import box_lnprior_batch
+
+    def f(q):
+        lp = box_lnprior_batch(q, bounds)
+        inside = np.isfinite(lp)
+        out = np.full(len(q), -np.inf)
+        if inside.any():
+            out[inside] = o.predict(y, q[inside])
+        return out
+    return f
+
+
+def test_device_draws_match_oracle_bit_for_bit(setup):
+    torch, g, o, y, bounds = setup
+    from alabi_amd import EnsembleSampler, _lib
+    from oracle.stretch_oracle import draw_step_randoms
+    for W in (10, 64, 257, 1024):
+        s = EnsembleSampler(W, 5, g, y, bounds, seed=0xDEADBEEFCAFE1234, live_dangerously=True)
+        s._ensure_ens()
+        for step in (0, 1, 12345678901):
+            order = torch.empty(W, dtype=torch.int32, device="cuda"); partner = torch.empty_like(order)
+            u_z = torch.empty(W, dtype=torch.float64, device="cuda"); u_acc = torch.empty_like(u_z)
+            n0 = C.c_int(0)
+            st = _lib.lib().alabi_ens_export_draws(s._ens, step, _lib.ptr(order), C.byref(n0), _lib.ptr(u_z),
+                                                   _lib.ptr(partner), _lib.ptr(u_acc), _lib.current_stream())
+            _lib.check(st, "export")
+            torch.cuda.synchronize()
+            ro, rn0, ruz, rp, rua = draw_step_randoms(0xDEADBEEFCAFE1234, step, W)
+            assert n0.value == rn0
+            assert np.array_equal(order.cpu().numpy(), ro)          # integer index arithmetic: bit exact
+            assert np.array_equal(partner.cpu().numpy(), rp)
+            assert np.array_equal(u_z.cpu().numpy(), ruz)            # 53-bit uniforms: bit exact
+            assert np.array_equal(u_acc.cpu().numpy(), rua)
+
+
+def test_step_with_injected_randoms(setup):
+    """Same (order, u_z, partner, u_acc) -> same partner indices, proposals, accept mask."""
+    torch, g, o, y, bounds = setup
+    from alabi_amd import EnsembleSampler, _lib
+    from oracle import stretch_oracle as so
+    W, d = 48, 5
+    rng = np.random.RandomState(4)
+    s = EnsembleSampler(W, d, g, y, bounds, seed=1)
+    coords = rng.uniform(-2.9, 2.9, (W, d))             # close to the walls: some proposals leave the box
+    lnp = _lnp(o, y, bounds)
+    logp_o = lnp(coords)
+    c_dev = torch.as_tensor(coords, device="cuda").clone()
+    lp_dev = s.compute_log_prob(c_dev)
+    assert np.max(np.abs(lp_dev.cpu().numpy() - logp_o)) < 1e-8 * (1 + np.max(np.abs(logp_o)))
+    nacc = torch.zeros(W, dtype=torch.int64, device="cuda")
+    n_out = 0
+    for it in range(30):
+        rs = np.random.RandomState(100 + it)
+        inds = np.arange(W) % 2; rs.shuffle(inds)
+        ids = np.arange(W)
+        order = np.concatenate([ids[inds == 0], ids[inds == 1]]).astype(np.int32); n0 = int((inds == 0).sum())
+        u_z = rs.rand(W); u_acc = rs.rand(W); partner = rs.randint(W // 2, size=W).astype(np.int32)
+        c_o, l_o, a_o = so.stretch_step_arrays(coords, logp_o, order, n0, u_z, partner, u_acc, lnp)
+        before = c_dev.cpu().numpy().copy()
+        t = lambda a: torch.as_tensor(a, device="cuda")  # noqa: E731
+        st = _lib.lib().alabi_ens_step_with_randoms(s._ens, _lib.ptr(c_dev), _lib.ptr(lp_dev), _lib.ptr(t(order)), n0,
+                                                    _lib.ptr(t(u_z)), _lib.ptr(t(partner)), _lib.ptr(t(u_acc)), 2.0,
+                                                    _lib.ptr(nacc), _lib.current_stream())
+        _lib.check(st, "step_with_randoms")
+        torch.cuda.synchronize()
+        c_g = c_dev.cpu().numpy(); l_g = lp_dev.cpu().numpy()
+        a_g = np.any(c_g != before, axis=1)
+        # knife-edge accepts (|lnpdiff - ln u| below the fp64 agreement of the two lnprobs) may differ; none expected
+        assert np.array_equal(a_g, a_o), f"accept mask differs at iteration {it}"
+        assert np.array_equal(c_g, c_o)                  # proposals are bit-identical (no FMA contraction)
+        assert np.max(np.abs(l_g - l_o)) < 1e-8 * (1 + np.max(np.abs(l_o[np.isfinite(l_o)])))
+        n_out += int(np.sum(~a_o))
+        coords, logp_o = c_o, l_o
+        lp_dev.copy_(torch.as_tensor(l_o, device="cuda"))   # keep the two states identical for the next step
+    assert int(nacc.sum()) > 0 and n_out > 0
+
+
+@pytest.mark.parametrize("W,nsteps,thin", [(32, 300, 1), (64, 257, 3), (33, 64, 1)])
+def test_production_run_matches_oracle_chain(setup, W, nsteps, thin):
+    """Counter-based draws + kernel sequence (graph replay + eager tail) == oracle run, step for step."""
+    torch, g, o, y, bounds = setup
+    from alabi_amd import EnsembleSampler
+    from oracle import stretch_oracle as so
+    rng = np.random.RandomState(W)
+    p0 = rng.uniform(-2, 2, (W, 5))
+    s = EnsembleSampler(W, 5, g, y, bounds, seed=77)
+    s.run_mcmc(p0, nsteps, thin_by=thin)
+    chain = s.get_chain()
+    chain_o, lp_o, nacc_o, _, _ = so.run_ensemble(p0, nsteps, _lnp(o, y, bounds), seed=77, thin_by=thin)
+    assert chain.shape == chain_o.shape
+    assert np.max(np.abs(chain - chain_o)) < 1e-7
+    assert np.max(np.abs(s.get_log_prob() - lp_o)) < 1e-7
+    assert np.array_equal(s._naccept.cpu().numpy(), nacc_o)
+    # continuing the run continues the counter (emcee: run_mcmc(None, n) resumes)
+    s.run_mcmc(None, 10 * thin, thin_by=thin)
+    chain_o2, _, _, _, _ = so.run_ensemble(chain_o[-1] if nsteps % thin == 0 else None, 10 * thin, _lnp(o, y, bounds),
+                                           seed=77, thin_by=thin, step0=nsteps) if nsteps % thin == 0 else (None,) * 5
+    if chain_o2 is not None:
+        assert np.max(np.abs(s.get_chain()[-10:] - chain_o2)) < 1e-7
+
+
+def test_graph_and_eager_paths_agree(setup, monkeypatch):
+    torch, g, o, y, bounds = setup
+    from alabi_amd import EnsembleSampler
+    p0 = np.random.RandomState(2).uniform(-2, 2, (40, 5))
+    monkeypatch.setenv("ALABI_ENS_GRAPH_STEPS", "64")
+    a = EnsembleSampler(40, 5, g, y, bounds, seed=5); a.run_mcmc(p0, 200)
+    monkeypatch.setenv("ALABI_ENS_GRAPH", "0")
+    b = EnsembleSampler(40, 5, g, y, bounds, seed=5); b.run_mcmc(p0, 200)
+    assert np.array_equal(a.get_chain(), b.get_chain())
+    assert np.array_equal(a.acceptance_fraction, b.acceptance_fraction)
+
+
+def test_sampler_statistics_on_gaussian_surrogate(setup):
+    """Size-independent property: the chain samples exp(surrogate) -- compare moments with the oracle chain."""
+    torch, g, o, y, bounds = setup
+    from alabi_amd import EnsembleSampler
+    W = 64
+    p0 = np.random.RandomState(8).uniform(-1, 1, (W, 5))
+    s = EnsembleSampler(W, 5, g, y, bounds, seed=3)
+    s.run_mcmc(p0, 4000)
+    flat = s.get_chain(discard=500, flat=True)
+    assert np.all(np.abs(flat.mean(axis=0)) < 0.5)
+    assert 0.15 < s.acceptance_fraction.mean() < 0.9
+    tau = s.get_autocorr_time(tol=0)
+    assert tau.shape == (5,) and np.all(np.isfinite(tau))
+    assert np.all(flat > -3.0) and np.all(flat < 3.0)      # the box prior is never violated

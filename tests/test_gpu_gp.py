@@ -1,0 +1,176 @@
+"""GPU parity: the HIP GP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64, stated per quantity):
+  K, kernel.get_value : 1e-13 relative (elementwise, exp + d FMAs)
+  L (factor)          : |L L^T - K| <= 1e-12 |K|   (L itself is not backward stable on ill-conditioned K)
+  alpha               : residual |K alpha - r| <= 1e-8 |r|     (cond(K) up to ~1e9 at nugget e^-12)
+  mu*                 : |dmu| / (|mu| + 1) <= 1e-8
+  var*                : |dvar| <= 1e-6 amp  (two algebraically equal formulas, error ~ cond(K) eps amp)
+  logdet / logL       : 1e-9 relative
+"""
+import numpy as np
+import pytest
+
+from conftest import make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_gpu():
+    import torch
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    return torch
+
+
+def _pair(X, y, h):
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    d = X.shape[1]
+    g = HipGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"])
+    g.compute(X)
+    o = OracleGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X)
+    return g, o
+
+
+@pytest.mark.parametrize("N,d,seed", [(50, 2, 0), (64, 1, 1), (65, 3, 2), (500, 5, 3), (777, 10, 4), (300, 20, 5), (130, 7, 6)])
+def test_factor_alpha_predict(torch_gpu, N, d, seed):
+    X, y, h = make_problem(N, d, seed)
+    g, o = _pair(X, y, h)
+    amp = np.exp(h["log_amp"])
+    K = o.get_matrix(X)
+    L = g.solver.get_factor().cpu().numpy()
+    assert np.all(np.triu(L, 1) == 0)
+    assert np.max(np.abs(L @ L.T - K)) <= 1e-12 * np.max(np.abs(K))
+    Xs = np.random.RandomState(seed + 100).uniform(-3.2, 3.2, (333, d))
+    mu, var = g.predict(y, Xs, return_var=True)
+    mu_o, var_o = o.predict(y, Xs, return_var=True)
+    alpha = g._alpha
+    r = y - h["mean"]
+    assert np.max(np.abs(K @ alpha - r)) <= 1e-8 * np.max(np.abs(r))
+    assert np.max(np.abs(mu - mu_o) / (np.abs(mu_o) + 1)) <= 1e-8
+    assert np.max(np.abs(var - var_o)) <= 1e-6 * amp
+    mu_only = g.predict(y, Xs, return_cov=False)
+    assert np.max(np.abs(mu_only - mu_o) / (np.abs(mu_o) + 1)) <= 1e-8
+    assert abs(g.solver.log_determinant - o.log_determinant) <= 1e-9 * abs(o.log_determinant) + 1e-9
+    assert abs(g.log_likelihood(y) - o.log_likelihood(y)) <= 1e-9 * abs(o.log_likelihood(y)) + 1e-7
+
+
+def test_headline_size_N2000_d10(torch_gpu):
+    X, y, h = make_problem(2000, 10, 3)
+    g, o = _pair(X, y, h)
+    Xs = np.random.RandomState(9).uniform(-3, 3, (5000, 10))       # > 4096 -> tiled mean kernel
+    mu_o, var_o = o.predict(y, Xs, return_var=True)
+    mu = g.predict(y, Xs, return_cov=False)
+    mu2, var = g.predict(y, Xs, return_var=True)
+    amp = np.exp(h["log_amp"])
+    assert np.max(np.abs(mu - mu_o) / (np.abs(mu_o) + 1)) <= 1e-8
+    assert np.max(np.abs(mu2 - mu_o) / (np.abs(mu_o) + 1)) <= 1e-8
+    assert np.max(np.abs(var - var_o)) <= 1e-6 * amp
+    small = g.predict(y, Xs[:100], return_cov=False)                # row-wise kernel
+    assert np.max(np.abs(small - mu_o[:100]) / (np.abs(mu_o[:100]) + 1)) <= 1e-8
+
+
+def test_kernel_get_value(torch_gpu):
+    from oracle.gp_oracle import sqexp_kernel
+    X, y, h = make_problem(150, 6, 7)
+    g, o = _pair(X, y, h)
+    X2 = np.random.RandomState(1).uniform(-3, 3, (70, 6))
+    K = g.kernel.get_value(X, X2)
+    np.testing.assert_allclose(K, sqexp_kernel(X, X2, h["log_amp"], h["log_M"]), rtol=1e-13, atol=1e-300)
+
+
+def test_known_answers_and_properties(torch_gpu):
+    X, y, h = make_problem(256, 3, 8, log_wn=-14.0)
+    g, o = _pair(X, y, h)
+    amp = np.exp(h["log_amp"])
+    mu, var = g.predict(y, X, return_var=True)
+    np.testing.assert_allclose(mu, y, atol=1e-3)                    # interpolation
+    assert np.all(np.abs(var) < 1e-3 * amp)                          # variance collapses at the data
+    far = np.full((3, 3), 400.0)
+    mu_f, var_f = g.predict(y, far, return_var=True)
+    assert np.allclose(mu_f, h["mean"], atol=1e-12) and np.allclose(var_f, amp, rtol=1e-14)
+    # linearity of the mean in y (same factor): mu(a y1 + b y2) - m = a (mu(y1)-m) + b (mu(y2)-m)
+    rng = np.random.RandomState(0)
+    y2 = rng.randn(len(y))
+    Xs = rng.uniform(-3, 3, (64, 3))
+    m1 = g.predict(y, Xs, return_cov=False) - h["mean"]
+    m2 = g.predict(y2, Xs, return_cov=False) - h["mean"]
+    m3 = g.predict(2.0 * y - 3.0 * y2 + h["mean"] * 2.0, Xs, return_cov=False) - h["mean"]
+    np.testing.assert_allclose(m3, 2.0 * m1 - 3.0 * m2, rtol=1e-7, atol=1e-7)
+
+
+def test_not_positive_definite_status(torch_gpu):
+    from alabi_amd import HipGP
+    X = np.zeros((70, 2)); X[:, 0] = np.arange(70) * 1e-9            # numerically identical points
+    g = HipGP(2, 0.0, -80.0, 0.0, [0.0, 0.0])
+    with pytest.raises(np.linalg.LinAlgError):
+        g.compute(X)
+    assert g.compute(X, quiet=True) is False
+    assert g.log_likelihood(np.zeros(70), quiet=True) == -np.inf
+    g.set_parameter_vector([0.0, -2.0, 0.0, 0.0, 0.0])               # a real nugget repairs it
+    assert g.compute(X) is True
+
+
+def test_parameter_protocol_pickle_and_growth(torch_gpu):
+    import copy
+    import pickle
+    X, y, h = make_problem(90, 2, 11)
+    g, o = _pair(X, y, h)
+    assert g.get_parameter_names() == o.get_parameter_names()
+    np.testing.assert_array_equal(g.get_parameter_vector(), o.get_parameter_vector())
+    Xs = np.random.RandomState(2).uniform(-3, 3, (17, 2))
+    ref = g.predict(y, Xs, return_cov=False)
+    g2 = pickle.loads(pickle.dumps(g))
+    np.testing.assert_allclose(g2.predict(y, Xs, return_cov=False), ref, rtol=1e-12)
+    g3 = copy.deepcopy(g)
+    p = g3.get_parameter_vector(); p[-1] += 0.3
+    g3.set_parameter_vector(p)
+    o.set_parameter_vector(p); o.recompute()
+    np.testing.assert_allclose(g3.predict(y, Xs, return_cov=False), o.predict(y, Xs), rtol=1e-8)
+    np.testing.assert_allclose(g.predict(y, Xs, return_cov=False), ref, rtol=1e-12)   # the copy did not alias
+    # capacity growth: refit on more points than the first handle held
+    X2, y2, _ = make_problem(400, 2, 12)
+    g.compute(X2)
+    o2 = type(o)(2, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X2)
+    np.testing.assert_allclose(g.predict(y2, Xs, return_cov=False), o2.predict(y2, Xs), rtol=1e-7, atol=1e-7)
+
+
+def test_utility_epilogue_against_golden(torch_gpu, golden):
+    from alabi_amd.utility import utility_eval_device
+    g = golden
+    for algo, key in (("bape", "util_bape"), ("agp", "util_agp"), ("jones", "util_jones")):
+        u = utility_eval_device(algo, g["util_theta"], g["util_bounds"], g["util_mu"], g["util_var"],
+                                float(g["util_y_best"])).cpu().numpy()
+        ref = g[key]
+        assert np.array_equal(np.isnan(u), np.isnan(ref))
+        inf = np.isinf(ref)
+        assert np.array_equal(u[inf], ref[inf])
+        fin = np.isfinite(ref)
+        np.testing.assert_allclose(u[fin], ref[fin], rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.parametrize("algo", ["bape", "agp", "jones"])
+def test_utility_scan_argmin(torch_gpu, algo):
+    from alabi_amd.utility import utility_scan
+    from oracle.utility_oracle import utility_batch
+    X, y, h = make_problem(400, 4, 21)
+    g, o = _pair(X, y, h)
+    bounds = np.array([[-3.0, 3.0]] * 4)
+    cand = np.random.RandomState(5).uniform(-3.3, 3.3, (20000, 4))    # some outside the box
+    best, val, idx, u, mu, var = utility_scan(g, y, cand, bounds, algo, y_best=float(y.max()), return_all=True)
+    mu_o, var_o = o.predict(y, cand, return_var=True)
+    u_dev = u.cpu().numpy()
+    # epilogue applied to the DEVICE (mu, var) must match the oracle formula exactly; arg-min over finite values
+    u_chk = utility_batch(algo, mu.cpu().numpy(), var.cpu().numpy(), cand, bounds, float(y.max()))
+    fin = np.isfinite(u_chk)
+    assert np.array_equal(np.isfinite(u_dev), fin)
+    np.testing.assert_allclose(u_dev[fin], u_chk[fin], rtol=1e-12)
+    assert idx == int(np.flatnonzero(fin)[np.argmin(u_dev[fin])]) and val == u_dev[idx]
+    np.testing.assert_array_equal(best, cand[idx])
+    # and the whole scan agrees with the oracle's own (mu, var) to conditioning
+    u_o = utility_batch(algo, mu_o, var_o, cand, bounds, float(y.max()))
+    both = fin & np.isfinite(u_o)
+    assert both.sum() > 0.5 * len(cand)
+    assert abs(u_dev[idx] - np.min(u_o[both])) < 1e-5 * (1 + abs(u_dev[idx]))

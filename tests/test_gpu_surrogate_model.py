@@ -1,0 +1,67 @@
+"""End-to-end SurrogateModel flow on the GPU (reference config C1: 2-D Rosenbrock, small N)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_init_gp_active_train_run_emcee(tmp_path):
+    import torch
+    from alabi_amd import SurrogateModel
+    from alabi_amd.benchmarks import rosenbrock
+    assert torch.cuda.is_available()
+    sm = SurrogateModel(lnlike_fn=rosenbrock["fn"], bounds=rosenbrock["bounds"], savedir=str(tmp_path),
+                        verbose=False, random_state=0)
+    with pytest.raises(ValueError):
+        SurrogateModel(lnlike_fn=None, bounds=rosenbrock["bounds"])
+    sm.init_samples(ntrain=50, ntest=20, sampler="uniform")
+    mse = sm.init_gp(kernel="ExpSquaredKernel", fit_amp=True, fit_mean=True, white_noise=-12, hyperopt_method="ml",
+                     gp_nopt=2)
+    assert np.isfinite(mse)
+    with pytest.raises(AssertionError):
+        sm.init_gp()
+    assert sm.gp.get_parameter_names()[0] == "mean:value" and len(sm.gp.get_parameter_vector()) == 3 + 2
+    n0 = sm.ntrain
+    sm.active_train(niter=6, algorithm="bape", gp_opt_freq=4, optimizer_kwargs={"ncand": 4096})
+    assert sm.ntrain == n0 + 6 and sm.nactive == 6 and len(sm.training_results["iteration"]) == 6
+    assert len(sm.training_results["gp_hyperparameter_opt_iteration"]) == 1
+    assert np.all(np.isfinite(sm.training_results["training_mse"]))
+    # surrogate likelihood: scalar for 1-D input, array for 2-D, and the cached form agrees
+    t = np.array([[0.1, 0.2], [1.0, 1.0], [-2.0, 3.0]])
+    a = sm.surrogate_log_likelihood(t)
+    assert a.shape == (3,) and np.isscalar(float(sm.surrogate_log_likelihood(t[0])))
+    cached = sm.create_cached_surrogate_likelihood()
+    np.testing.assert_allclose(cached(t), a, rtol=1e-8, atol=1e-8)
+    mu, var = sm.surrogate_log_likelihood(t, return_var=True)
+    np.testing.assert_allclose(mu, a, rtol=1e-10)
+    # lnprob = surrogate + box prior
+    sm.prior_fn = lambda th: 0.0  # noqa: E731
+    sm.like_fn = sm.surrogate_log_likelihood
+    assert np.allclose(sm.lnprob(t[1]), a[1])
+    sm.run_emcee(nwalkers=16, nsteps=600, min_ess=200)
+    assert sm.emcee_run and sm.emcee_samples.shape[1] == 2 and sm.emcee_samples.shape[0] >= 200
+    assert 0.05 < sm.acc_frac < 0.95 and np.isfinite(sm.autcorr_time)
+    assert sm.emcee_samples_full.shape == (600, 16, 2)
+    b = np.asarray(rosenbrock["bounds"], dtype=float)
+    assert np.all(sm.emcee_samples > b[:, 0]) and np.all(sm.emcee_samples < b[:, 1])
+    assert sm.run_mcmc.__func__ is sm.run_emcee.__func__
+    with pytest.raises(NotImplementedError):
+        sm.run_emcee(like_fn=lambda th: 0.0)
+    # reference-style scipy acquisition optimisation still works (one GP prediction per objective call)
+    sm.active_train(niter=1, algorithm="agp", obj_opt_method="nelder-mead", nopt=1, optimizer_kwargs={"max_iter": 15})
+    assert sm.ntrain == n0 + 7
+
+
+def test_cv_hyperopt_and_pickle(tmp_path):
+    import pickle
+    from alabi_amd import SurrogateModel
+    from alabi_amd.benchmarks import gaussian_2d
+    sm = SurrogateModel(lnlike_fn=gaussian_2d["fn"], bounds=gaussian_2d["bounds"], savedir=str(tmp_path),
+                        verbose=False, random_state=1)
+    sm.init_samples(ntrain=40)
+    sm.init_gp(hyperopt_method="cv", cv_n_candidates=6, cv_stage2_candidates=4, cv_stage3_candidates=3)
+    t = np.array([[0.4, 0.6]])
+    ref = sm.surrogate_log_likelihood(t)
+    sm.save()
+    sm2 = pickle.load(open(tmp_path / "surrogate_model.pkl", "rb"))
+    np.testing.assert_allclose(sm2.surrogate_log_likelihood(t), ref, rtol=1e-10)
