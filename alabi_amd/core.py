@@ -435,11 +435,19 @@ class SurrogateModel(object):
                 p0 = ut.prior_sampler(bounds=self.hp_bounds, nsample=self.gp_nopt, sampler="lhs", random_state=self._seed())
                 p0[0] = current
                 res = min((_run(p) for p in p0), key=lambda r: r.fun)
-            op_gp = self.set_hyperparameter_vector(gp, res.x)
-            op_gp.compute(_theta)
+            best = res.x
+            if not (np.all(np.isfinite(best)) and np.isfinite(res.fun) and res.fun < 1e25):
+                # e.g. the incumbent lies outside the reference's amplitude box (built from the linear var(y),
+                # core.py:654) and every point inside it overflows: keep the incumbent, as the CV branch does
+                print("Warning: ML hyper-parameter search found no valid point; keeping current hyperparameters.")
+                best = current
+            op_gp = self.set_hyperparameter_vector(gp, best)
+            if not op_gp.compute(_theta, quiet=True):
+                op_gp = self.set_hyperparameter_vector(gp, current)
+                op_gp.compute(_theta)
             if self.verbose:
-                print(f"GP ML fit: -logL(+reg) {nll(current):.4f} -> {res.fun:.4f} in {res.nit} iterations")
-                self.set_hyperparameter_vector(gp, res.x)
+                print(f"GP ML fit: -logL(+reg) {nll(current):.4f} -> {nll(best):.4f} in {res.nit} iterations")
+                self.set_hyperparameter_vector(gp, best)
                 gp.compute(_theta)
         else:
             if self.verbose:

@@ -102,7 +102,13 @@ ens_half_kernel(HalfArgs p, DimVec inv_len, DimVec lo, DimVec hi) {
     const int* S = p.split == 0 ? p.order : p.order + p.n0;
     const int* C = p.split == 0 ? p.order + p.n0 : p.order;
     const int w = S[p.part_begin + blockIdx.x];
-    const int cw = C[p.partner[w]];
+    const int nC = p.split == 0 ? p.W - p.n0 : p.n0;
+    // caller-supplied lists (test entry) are range-checked: a bad index must not become a wild access
+    if ((unsigned)w >= (unsigned)p.W) return;
+    const int pr = p.partner[w];
+    if ((unsigned)pr >= (unsigned)nC) return;
+    const int cw = C[pr];
+    if ((unsigned)cw >= (unsigned)p.W) return;
     // z = ((a-1) u + 1)^2 / a, evaluated in numpy's operation order (no contraction)
     const double t1 = (p.a - 1.0) * p.u_z[w] + 1.0;
     const double zz = (t1 * t1) / p.a;

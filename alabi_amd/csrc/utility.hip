@@ -13,7 +13,12 @@ namespace alabi {
 __device__ inline double utility_value(int algo, double mu, double var, double y_best) {
     if (algo == ALABI_UTILITY_BAPE) {
         // -((2 mu + var) + logsubexp(var, 0)); logsubexp = -inf when var <= 0  -> +inf
-        double lse = (var <= 0.0) ? -INFINITY : var + log(1.0 - exp(0.0 - var));
+        // The reference evaluates log(1 - exp(-var)) literally (utility.py:504), which cancels for small
+        // var.  To land on the same side of that cancellation, exp(-var) is formed as RN(1 + expm1(-var))
+        // for small var: that is the correctly rounded exponential whenever |expm1| << 1 (exactly 1.0 below
+        // 2^-54, 1 - 2^-53 just above it); the absolute error of the utility is then eps / (1 - e^-var).
+        double em = (var < 0.0009765625) ? 1.0 + expm1(0.0 - var) : exp(0.0 - var);
+        double lse = (var <= 0.0) ? -INFINITY : var + log(1.0 - em);
         return -((2.0 * mu + var) + lse);
     } else if (algo == ALABI_UTILITY_AGP) {
         // -(mu + 0.5 log(2 pi e var)); log of a negative variance is NaN, of zero -inf

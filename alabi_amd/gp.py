@@ -265,13 +265,16 @@ class HipGP:
 
     def _set_y(self, y):
         if isinstance(y, torch.Tensor):
-            yd = _to_dev(y).reshape(-1)
-            same = False
+            key = (y.data_ptr(), y._version, tuple(y.shape))
+            same = self._y_set and getattr(self, "_y_key", None) == key
+            yd = None if same else _to_dev(y).reshape(-1)
             yh = None
+            self._y_key = key
         else:
             yh = np.asarray(y, dtype=np.float64).ravel()
             same = self._y_set and self._y is not None and np.array_equal(yh, self._y)
             yd = None
+            self._y_key = None
         if same:
             return
         if yd is None:

@@ -83,9 +83,10 @@ def test_step_with_injected_randoms(setup):
         u_z = rs.rand(W); u_acc = rs.rand(W); partner = rs.randint(W // 2, size=W).astype(np.int32)
         c_o, l_o, a_o = so.stretch_step_arrays(coords, logp_o, order, n0, u_z, partner, u_acc, lnp)
         before = c_dev.cpu().numpy().copy()
-        t = lambda a: torch.as_tensor(a, device="cuda")  # noqa: E731
-        st = _lib.lib().alabi_ens_step_with_randoms(s._ens, _lib.ptr(c_dev), _lib.ptr(lp_dev), _lib.ptr(t(order)), n0,
-                                                    _lib.ptr(t(u_z)), _lib.ptr(t(partner)), _lib.ptr(t(u_acc)), 2.0,
+        # keep the device copies alive until the kernels have run (the call is asynchronous)
+        d_order, d_uz, d_partner, d_uacc = (torch.as_tensor(a, device="cuda") for a in (order, u_z, partner, u_acc))
+        st = _lib.lib().alabi_ens_step_with_randoms(s._ens, _lib.ptr(c_dev), _lib.ptr(lp_dev), _lib.ptr(d_order), n0,
+                                                    _lib.ptr(d_uz), _lib.ptr(d_partner), _lib.ptr(d_uacc), 2.0,
                                                     _lib.ptr(nacc), _lib.current_stream())
         _lib.check(st, "step_with_randoms")
         torch.cuda.synchronize()

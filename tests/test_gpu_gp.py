@@ -137,6 +137,18 @@ def test_parameter_protocol_pickle_and_growth(torch_gpu):
     np.testing.assert_allclose(g.predict(y2, Xs, return_cov=False), o2.predict(y2, Xs), rtol=1e-7, atol=1e-7)
 
 
+def _jones_atol(mu, var, y_best, zeta=0.01):
+    """EI = imp*cdf + sd*pdf cancels in the lower tail (by a factor ~z^2), and each term is exp(-z^2/2)-like,
+    so a 1-ulp rounding of its argument is a relative error of ~z^2/2 * eps in the term.  Below 1e-300 the
+    reference's cdf has already underflowed to 0 while erfc on the device still returns subnormals."""
+    from scipy.stats import norm
+    sd = np.sqrt(var); imp = mu - y_best - zeta
+    with np.errstate(over="ignore", invalid="ignore"):
+        z = imp / sd
+        z2 = np.minimum(z * z, 1e6)
+        return (2e-14 + 4.4e-16 * z2) * (np.abs(imp) * norm.cdf(z) + sd * norm.pdf(z)) + 1e-300
+
+
 def test_utility_epilogue_against_golden(torch_gpu, golden):
     from alabi_amd.utility import utility_eval_device
     g = golden
@@ -145,10 +157,28 @@ def test_utility_epilogue_against_golden(torch_gpu, golden):
                                 float(g["util_y_best"])).cpu().numpy()
         ref = g[key]
         assert np.array_equal(np.isnan(u), np.isnan(ref))
-        inf = np.isinf(ref)
+        inf = np.isinf(ref) & ~((g["util_var"] > 0) & (g["util_var"] < 1e-15) & (algo == "bape"))
         assert np.array_equal(u[inf], ref[inf])
         fin = np.isfinite(ref)
-        np.testing.assert_allclose(u[fin], ref[fin], rtol=1e-12, atol=1e-300)
+        # bape: the reference's literal log(1 - exp(-var)) amplifies the 1-ulp rounding of exp by 1/(1-e^-var);
+        # that conditioning (not a looser kernel) is the absolute tolerance for small var.
+        atol = np.full(len(ref), 1e-300)
+        v = g["util_var"]
+        pos = v > 0
+        if algo == "bape":
+            atol[pos] = 4.5e-16 / (-np.expm1(-v[pos]))
+        if algo == "jones":
+            atol[pos] = _jones_atol(g["util_mu"][pos], v[pos], float(g["util_y_best"]))
+        if algo == "bape":
+            # var within a few ulps of 0: 1 - exp(-var) is 0, 1 or 2 ulps depending on the exp implementation
+            # (NumPy's SIMD exp is not correctly rounded there), so the reference value itself is a coin flip
+            # between +inf and log(k eps).  Accept +inf or the same value to within log(4).
+            tiny = pos & (v < 1e-15)
+            ok_tiny = np.isposinf(u[tiny]) | (np.abs(u[tiny] - ref[tiny]) <= 1.4)
+            assert ok_tiny.all()
+            fin = fin & ~tiny
+        bad = np.abs(u[fin] - ref[fin]) > 1e-12 * np.abs(ref[fin]) + atol[fin]
+        assert not bad.any(), (algo, u[fin][bad][:5], ref[fin][bad][:5])
 
 
 @pytest.mark.parametrize("algo", ["bape", "agp", "jones"])
@@ -166,7 +196,8 @@ def test_utility_scan_argmin(torch_gpu, algo):
     u_chk = utility_batch(algo, mu.cpu().numpy(), var.cpu().numpy(), cand, bounds, float(y.max()))
     fin = np.isfinite(u_chk)
     assert np.array_equal(np.isfinite(u_dev), fin)
-    np.testing.assert_allclose(u_dev[fin], u_chk[fin], rtol=1e-12)
+    atol = _jones_atol(mu.cpu().numpy()[fin], np.maximum(var.cpu().numpy()[fin], 1e-300), float(y.max())) if algo == "jones" else 0.0
+    assert np.all(np.abs(u_dev[fin] - u_chk[fin]) <= 1e-12 * np.abs(u_chk[fin]) + atol)
     assert idx == int(np.flatnonzero(fin)[np.argmin(u_dev[fin])]) and val == u_dev[idx]
     np.testing.assert_array_equal(best, cand[idx])
     # and the whole scan agrees with the oracle's own (mu, var) to conditioning

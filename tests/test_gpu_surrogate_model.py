@@ -52,6 +52,22 @@ def test_init_gp_active_train_run_emcee(tmp_path):
     assert sm.ntrain == n0 + 7
 
 
+def test_ml_hyperopt_improves_likelihood(tmp_path):
+    from alabi_amd import SurrogateModel, gp_utils
+    from alabi_amd.benchmarks import gaussian_2d
+    sm = SurrogateModel(lnlike_fn=gaussian_2d["fn"], bounds=gaussian_2d["bounds"], savedir=str(tmp_path),
+                        verbose=False, random_state=3, cache=False)
+    sm.init_samples(ntrain=60)
+    sm.init_gp(hyperopt_method="ml", gp_nopt=1, regularize=True)
+    p_fit = sm.gp.get_parameter_vector()
+    obj = lambda p: (-sm.gp.log_likelihood(sm._y) if not sm.gp.set_parameter_vector(p) else 0) + \
+        gp_utils.regularization_term(p, sm.hp_length_indices)  # noqa: E731
+    f_fit = obj(p_fit)
+    f_init = obj(sm.initial_gp_hyperparameters)
+    assert np.isfinite(f_fit) and f_fit <= f_init + 1e-6
+    assert np.all(p_fit >= sm.hp_bounds[:, 0] - 1e-9) and np.all(p_fit <= sm.hp_bounds[:, 1] + 1e-9)
+
+
 def test_cv_hyperopt_and_pickle(tmp_path):
     import pickle
     from alabi_amd import SurrogateModel
