@@ -45,15 +45,15 @@ SIGNATURES = {
     "alabi_kernel_matrix": (_i, [_vp, _i, _vp, _i, _i, _d, _pd, _vp, _vp]),
     "alabi_utility_scan": (_i, [_vp, _i, _vp, _ll, _pd, _d, _vp, _vp, _vp, _pd, _pll, _vp]),
     "alabi_utility_eval": (_i, [_i, _vp, _ll, _i, _pd, _d, _vp, _vp, _vp, _vp]),
-    "alabi_ens_create": (_i, [_vp, _i, _i, _pd, _ull, C.POINTER(_vp)]),
+    "alabi_ens_create": (_i, [_vp, _i, _i, _i, _pd, _ull, C.POINTER(_vp)]),
     "alabi_ens_destroy": (_i, [_vp]),
     "alabi_ens_lnprob": (_i, [_vp, _vp, _vp, _vp]),
     "alabi_ens_run": (_i, [_vp, _vp, _vp, _ll, _ll, _i, _d, _vp, _vp, _vp, _vp]),
-    "alabi_ens_draw": (_i, [_vp, _ll, _i, _vp]),
-    "alabi_ens_half_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _vp, _vp]),
+    "alabi_ens_draw": (_i, [_vp, _ll, _i, _d, _vp]),
+    "alabi_ens_half_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "alabi_ens_step_lists": (_i, [_vp, _i, _vp, _pi, _vp]),
     "alabi_ens_step_with_randoms": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp]),
-    "alabi_ens_export_draws": (_i, [_vp, _ll, _vp, _pi, _vp, _vp, _vp, _vp]),
+    "alabi_ens_export_draws": (_i, [_vp, _ll, _d, _vp, _pi, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

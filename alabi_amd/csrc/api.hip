@@ -260,24 +260,60 @@ int alabi_utility_scan(alabi_gp* gp, int algo, const double* Xs, long long M, co
 }
 
 // ---------------------------------------------------------------------------- ensemble
-int alabi_ens_create(alabi_gp* gp, int W, int d, const double* bounds, unsigned long long seed, alabi_ens** out) {
-    if (!gp || !out || !bounds || W < 2 || W > 8192 || d != gp->d) return ALABI_BAD_ARGUMENT;
+static void free_draws(DrawBuffers& b) {
+    if (b.order) (void)hipFree(b.order);
+    if (b.cw) (void)hipFree(b.cw);
+    if (b.zz) (void)hipFree(b.zz);
+    if (b.lnfac) (void)hipFree(b.lnfac);
+    if (b.lnu) (void)hipFree(b.lnu);
+    if (b.partner) (void)hipFree(b.partner);
+    if (b.u_z) (void)hipFree(b.u_z);
+    if (b.u_acc) (void)hipFree(b.u_acc);
+    b = DrawBuffers{};
+}
+
+static DrawBuffers offset_draws(const DrawBuffers& b, size_t off) {
+    DrawBuffers r = b;
+    r.order += off; r.cw += off; r.zz += off; r.lnfac += off; r.lnu += off;
+    r.partner += off; r.u_z += off; r.u_acc += off;
+    return r;
+}
+
+int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* bounds, unsigned long long seed,
+                     alabi_ens** out) {
+    if (!gp || !out || !bounds || W < 2 || W > 8192 || d != gp->d || n_ensembles < 1 || n_ensembles > 4096)
+        return ALABI_BAD_ARGUMENT;
+    if ((long long)W * n_ensembles > (1LL << 22)) return ALABI_BAD_ARGUMENT;
     alabi_ens* e = new (std::nothrow) alabi_ens();
     if (!e) return ALABI_BAD_ARGUMENT;
-    e->gp = gp; e->W = W; e->d = d; e->seed = seed;
-    fill_dimvec(e->lo, bounds, d, 2, 0, 0.0);
-    fill_dimvec(e->hi, bounds, d, 2, 1, 0.0);
-    long long cap = (4LL << 20) / W;
+    e->gp = gp; e->W = W; e->d = d; e->E = n_ensembles; e->seed = seed;
+    for (int k = 0; k < ALABI_MAX_DIM; ++k) {
+        e->lo[k] = (k < d) ? bounds[2 * k] : 0.0;
+        e->hi[k] = (k < d) ? bounds[2 * k + 1] : 0.0;
+    }
+    e->threads = 1024;
+    if (const char* env = getenv("ALABI_ENS_THREADS")) {
+        int v = atoi(env);
+        if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) e->threads = v;
+    }
+    const long long WT = (long long)W * n_ensembles;
+    long long cap = (4LL << 20) / WT;
     if (cap > 1024) cap = 1024;
     if (cap < 16) cap = 16;
     e->chunk_cap = (int)cap;
-    const size_t n = (size_t)e->chunk_cap * W;
+    const size_t n = (size_t)e->chunk_cap * WT;
+    DrawBuffers& b = e->draws;
     hipError_t err = hipSuccess;
-    if (err == hipSuccess) err = hipMalloc(&e->order, n * sizeof(int));
-    if (err == hipSuccess) err = hipMalloc(&e->partner, n * sizeof(int));
-    if (err == hipSuccess) err = hipMalloc(&e->u_z, n * sizeof(double));
-    if (err == hipSuccess) err = hipMalloc(&e->u_acc, n * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc(&b.order, n * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&b.cw, n * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&b.zz, n * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc(&b.lnfac, n * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc(&b.lnu, n * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc(&b.partner, n * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&b.u_z, n * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc(&b.u_acc, n * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&e->run_state, 4 * sizeof(long long));
+    if (err == hipSuccess) err = hipMalloc(&e->consts, 3 * ALABI_MAX_DIM * sizeof(double));
     if (err != hipSuccess) {
         alabi_ens_destroy(e);
         return hip_fail(err, "hipMalloc(ensemble buffers)", __FILE__, __LINE__);
@@ -289,48 +325,62 @@ int alabi_ens_create(alabi_gp* gp, int W, int d, const double* bounds, unsigned 
 int alabi_ens_destroy(alabi_ens* e) {
     if (!e) return ALABI_OK;
     if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
-    if (e->order) (void)hipFree(e->order);
-    if (e->partner) (void)hipFree(e->partner);
-    if (e->u_z) (void)hipFree(e->u_z);
-    if (e->u_acc) (void)hipFree(e->u_acc);
+    free_draws(e->draws);
     if (e->run_state) (void)hipFree(e->run_state);
+    if (e->consts) (void)hipFree(e->consts);
     delete e;
+    return ALABI_OK;
+}
+
+// (inv_len, lo, hi) live in device memory; refreshed whenever the GP's hyper-parameters changed.
+static int sync_consts(alabi_ens* e, hipStream_t s) {
+    if (e->consts_gen == e->gp->gen) return ALABI_OK;
+    double host[3 * ALABI_MAX_DIM];
+    for (int k = 0; k < ALABI_MAX_DIM; ++k) {
+        host[k] = e->gp->inv_len.v[k];
+        host[ALABI_MAX_DIM + k] = e->lo[k];
+        host[2 * ALABI_MAX_DIM + k] = e->hi[k];
+    }
+    ALABI_HIP_CHECK(hipMemcpyAsync(e->consts, host, sizeof(host), hipMemcpyHostToDevice, s));
+    ALABI_HIP_CHECK(hipStreamSynchronize(s));  // `host` is a stack buffer
+    e->consts_gen = e->gp->gen;
     return ALABI_OK;
 }
 
 int alabi_ens_lnprob(alabi_ens* e, const double* coords, double* logp, void* stream) {
     if (!e || !coords || !logp) return ALABI_BAD_ARGUMENT;
     if (!e->gp->computed || !e->gp->has_alpha) return ALABI_NOT_COMPUTED;
-    return launch_ens_lnprob(e, coords, e->W, logp, as_stream(stream));
+    int st = sync_consts(e, as_stream(stream));
+    if (st != ALABI_OK) return st;
+    return launch_ens_lnprob(e, coords, e->W * e->E, logp, as_stream(stream));
 }
 
-static HalfArgs base_args(alabi_ens* e, double* coords, double* logp, double a) {
+static HalfArgs base_args(alabi_ens* e, double* coords, double* logp) {
     HalfArgs h{};
     alabi_gp* gp = e->gp;
-    h.coords = coords; h.logp = logp;
+    h.coords = coords; h.logp = logp; h.consts = e->consts;
     h.Xt = gp->Xt; h.alpha = gp->alpha; h.Npad = gp->Npad;
     h.amp = std::exp(gp->log_amp); h.mean = gp->mean;
     h.W = e->W; h.d = e->d; h.n0 = (e->W + 1) / 2;
-    h.a = a; h.thin_by = 1; h.run_state = e->run_state;
+    h.thin_by = 1; h.run_state = e->run_state;
     return h;
 }
 
 static int set_run_state(alabi_ens* e, long long step0, long long done, hipStream_t s) {
     long long host[2] = {step0, done};
     ALABI_HIP_CHECK(hipMemcpyAsync(e->run_state, host, sizeof(host), hipMemcpyHostToDevice, s));
-    // the source is a stack buffer: make sure the copy has read it before returning
-    ALABI_HIP_CHECK(hipStreamSynchronize(s));
+    ALABI_HIP_CHECK(hipStreamSynchronize(s));  // `host` is a stack buffer
     return ALABI_OK;
 }
 
 // enqueue `n` steps that consume the chunk buffers (draw + 2n half steps + advance)
-static int enqueue_chunk(alabi_ens* e, HalfArgs h, int n, hipStream_t s) {
+static int enqueue_chunk(alabi_ens* e, HalfArgs h, int n, double a, hipStream_t s) {
     int st;
-    if ((st = launch_ens_draw(e, n, s)) != ALABI_OK) return st;
+    if ((st = launch_ens_draw(e, n, a, s)) != ALABI_OK) return st;
     const int n0 = h.n0, n1 = e->W - n0;
+    const size_t WT = (size_t)e->W * e->E;
     for (int t = 0; t < n; ++t) {
-        const size_t off = (size_t)t * e->W;
-        h.order = e->order + off; h.u_z = e->u_z + off; h.partner = e->partner + off; h.u_acc = e->u_acc + off;
+        h.rec = offset_draws(e->draws, (size_t)t * WT);
         h.local_t = t; h.part_begin = 0;
         h.split = 0;
         if ((st = launch_ens_half_args(e, h, n0, s)) != ALABI_OK) return st;
@@ -347,8 +397,9 @@ int alabi_ens_run(alabi_ens* e, double* coords, double* logp, long long step0, l
     if (nsteps == 0) return ALABI_OK;
     hipStream_t s = as_stream(stream);
     int st;
+    if ((st = sync_consts(e, s)) != ALABI_OK) return st;
     if ((st = set_run_state(e, step0, 0, s)) != ALABI_OK) return st;
-    HalfArgs h = base_args(e, coords, logp, a);
+    HalfArgs h = base_args(e, coords, logp);
     h.chain = chain; h.chain_logp = chain_logp; h.n_accept = n_accept; h.thin_by = thin_by;
 
     const char* env = getenv("ALABI_ENS_GRAPH");
@@ -366,14 +417,13 @@ int alabi_ens_run(alabi_ens* e, double* coords, double* logp, long long step0, l
             if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
             hipGraph_t graph = nullptr;
             ALABI_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            st = enqueue_chunk(e, h, gsteps, s);
+            st = enqueue_chunk(e, h, gsteps, a, s);
             hipError_t ce = hipStreamEndCapture(s, &graph);
             if (st != ALABI_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
             if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture", __FILE__, __LINE__);
             hipError_t ie = hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             if (ie != hipSuccess) { e->graph_exec = nullptr; return hip_fail(ie, "hipGraphInstantiate", __FILE__, __LINE__); }
-            memset(&e->graph_key, 0, sizeof(e->graph_key));
             e->graph_key = key;
             e->graph_steps = gsteps;
         }
@@ -384,38 +434,39 @@ int alabi_ens_run(alabi_ens* e, double* coords, double* logp, long long step0, l
     }
     while (remaining > 0) {
         const int n = (int)(remaining < e->chunk_cap ? remaining : e->chunk_cap);
-        if ((st = enqueue_chunk(e, h, n, s)) != ALABI_OK) return st;
+        if ((st = enqueue_chunk(e, h, n, a, s)) != ALABI_OK) return st;
         remaining -= n;
     }
     return ALABI_OK;
 }
 
-int alabi_ens_draw(alabi_ens* e, long long step0, int nsteps, void* stream) {
-    if (!e || nsteps <= 0 || nsteps > e->chunk_cap) return ALABI_BAD_ARGUMENT;
+int alabi_ens_draw(alabi_ens* e, long long step0, int nsteps, double a, void* stream) {
+    if (!e || nsteps <= 0 || nsteps > e->chunk_cap || !(a > 1.0)) return ALABI_BAD_ARGUMENT;
     hipStream_t s = as_stream(stream);
     int st;
     if ((st = set_run_state(e, step0, 0, s)) != ALABI_OK) return st;
-    e->drawn_step0 = step0; e->drawn_n = nsteps;
-    return launch_ens_draw(e, nsteps, s);
+    e->drawn_n = nsteps;
+    return launch_ens_draw(e, nsteps, a, s);
 }
 
 int alabi_ens_half_step(alabi_ens* e, double* coords, double* logp, int t, int split, int part_begin, int part_end,
-                        double a, long long* n_accept, void* stream) {
-    if (!e || !coords || !logp || t < 0 || t >= e->drawn_n || (split != 0 && split != 1) || !(a > 1.0))
+                        long long* n_accept, void* stream) {
+    if (!e || !coords || !logp || t < 0 || t >= e->drawn_n || (split != 0 && split != 1) || e->E != 1)
         return ALABI_BAD_ARGUMENT;
     if (!e->gp->computed || !e->gp->has_alpha) return ALABI_NOT_COMPUTED;
-    HalfArgs h = base_args(e, coords, logp, a);
+    int st = sync_consts(e, as_stream(stream));
+    if (st != ALABI_OK) return st;
+    HalfArgs h = base_args(e, coords, logp);
     const int nS = split == 0 ? h.n0 : e->W - h.n0;
     if (part_begin < 0 || part_end > nS || part_begin > part_end) return ALABI_BAD_ARGUMENT;
-    const size_t off = (size_t)t * e->W;
-    h.order = e->order + off; h.u_z = e->u_z + off; h.partner = e->partner + off; h.u_acc = e->u_acc + off;
+    h.rec = offset_draws(e->draws, (size_t)t * e->W);
     h.local_t = t; h.split = split; h.part_begin = part_begin; h.n_accept = n_accept;
     return launch_ens_half_args(e, h, part_end - part_begin, as_stream(stream));
 }
 
 int alabi_ens_step_lists(alabi_ens* e, int t, int* order_out, int* n0, void* stream) {
-    if (!e || t < 0 || t >= e->drawn_n || !order_out || !n0) return ALABI_BAD_ARGUMENT;
-    ALABI_HIP_CHECK(hipMemcpyAsync(order_out, e->order + (size_t)t * e->W, (size_t)e->W * sizeof(int),
+    if (!e || t < 0 || t >= e->drawn_n || !order_out || !n0 || e->E != 1) return ALABI_BAD_ARGUMENT;
+    ALABI_HIP_CHECK(hipMemcpyAsync(order_out, e->draws.order + (size_t)t * e->W, (size_t)e->W * sizeof(int),
                                    hipMemcpyDeviceToDevice, as_stream(stream)));
     *n0 = (e->W + 1) / 2;
     return ALABI_OK;
@@ -424,31 +475,35 @@ int alabi_ens_step_lists(alabi_ens* e, int t, int* order_out, int* n0, void* str
 int alabi_ens_step_with_randoms(alabi_ens* e, double* coords, double* logp, const int* order, int n0,
                                 const double* u_z, const int* partner, const double* u_acc, double a,
                                 long long* n_accept, void* stream) {
-    if (!e || !coords || !logp || !order || !u_z || !partner || !u_acc || n0 < 0 || n0 > e->W || !(a > 1.0))
+    if (!e || !coords || !logp || !order || !u_z || !partner || !u_acc || n0 < 0 || n0 > e->W || !(a > 1.0) || e->E != 1)
         return ALABI_BAD_ARGUMENT;
     if (!e->gp->computed || !e->gp->has_alpha) return ALABI_NOT_COMPUTED;
     hipStream_t s = as_stream(stream);
-    HalfArgs h = base_args(e, coords, logp, a);
-    h.order = order; h.n0 = n0; h.u_z = u_z; h.partner = partner; h.u_acc = u_acc; h.n_accept = n_accept;
-    h.local_t = 0; h.part_begin = 0;
     int st;
+    if ((st = sync_consts(e, s)) != ALABI_OK) return st;
+    if ((st = launch_ens_prep(e, order, n0, u_z, partner, u_acc, a, s)) != ALABI_OK) return st;
+    e->drawn_n = 0;  // row 0 of the draw buffers now holds caller data
+    HalfArgs h = base_args(e, coords, logp);
+    h.rec = e->draws; h.n0 = n0; h.n_accept = n_accept; h.local_t = 0; h.part_begin = 0;
     h.split = 0;
     if ((st = launch_ens_half_args(e, h, n0, s)) != ALABI_OK) return st;
     h.split = 1;
     return launch_ens_half_args(e, h, e->W - n0, s);
 }
 
-int alabi_ens_export_draws(alabi_ens* e, long long step, int* order, int* n0, double* u_z, int* partner,
-                           double* u_acc, void* stream) {
+int alabi_ens_export_draws(alabi_ens* e, long long step, double a, int* order, int* n0, double* u_z, int* partner,
+                           double* u_acc, int* cw, double* zz, void* stream) {
     if (!e || !order || !n0 || !u_z || !partner || !u_acc) return ALABI_BAD_ARGUMENT;
     hipStream_t s = as_stream(stream);
     int st;
-    if ((st = alabi_ens_draw(e, step, 1, stream)) != ALABI_OK) return st;
-    const size_t W = e->W;
-    ALABI_HIP_CHECK(hipMemcpyAsync(order, e->order, W * sizeof(int), hipMemcpyDeviceToDevice, s));
-    ALABI_HIP_CHECK(hipMemcpyAsync(partner, e->partner, W * sizeof(int), hipMemcpyDeviceToDevice, s));
-    ALABI_HIP_CHECK(hipMemcpyAsync(u_z, e->u_z, W * sizeof(double), hipMemcpyDeviceToDevice, s));
-    ALABI_HIP_CHECK(hipMemcpyAsync(u_acc, e->u_acc, W * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if ((st = alabi_ens_draw(e, step, 1, a, stream)) != ALABI_OK) return st;
+    const size_t WT = (size_t)e->W * e->E;
+    ALABI_HIP_CHECK(hipMemcpyAsync(order, e->draws.order, WT * sizeof(int), hipMemcpyDeviceToDevice, s));
+    ALABI_HIP_CHECK(hipMemcpyAsync(partner, e->draws.partner, WT * sizeof(int), hipMemcpyDeviceToDevice, s));
+    ALABI_HIP_CHECK(hipMemcpyAsync(u_z, e->draws.u_z, WT * sizeof(double), hipMemcpyDeviceToDevice, s));
+    ALABI_HIP_CHECK(hipMemcpyAsync(u_acc, e->draws.u_acc, WT * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (cw) ALABI_HIP_CHECK(hipMemcpyAsync(cw, e->draws.cw, WT * sizeof(int), hipMemcpyDeviceToDevice, s));
+    if (zz) ALABI_HIP_CHECK(hipMemcpyAsync(zz, e->draws.zz, WT * sizeof(double), hipMemcpyDeviceToDevice, s));
     *n0 = (e->W + 1) / 2;
     return ALABI_OK;
 }

@@ -66,19 +66,32 @@ struct alabi_gp {
     size_t scan_bytes = 0;
 };
 
+namespace alabi {
+// Per-chunk draw buffers, all [chunk_cap, E, W]; the first five are the proposal records in LIST order
+// (per ensemble: set 0 then set 1), the last three keep the raw draws for export / tests.
+struct DrawBuffers {
+    int* order;      // global walker id at each list position
+    int* cw;         // global id of the partner walker drawn for that position
+    double* zz;      // stretch factor z
+    double* lnfac;   // (d-1) ln z
+    double* lnu;     // ln u'
+    int* partner;    // raw partner index into the complementary list (by list position)
+    double* u_z;     // raw uniforms (by list position)
+    double* u_acc;
+};
+}  // namespace alabi
+
 struct alabi_ens {
     alabi_gp* gp = nullptr;
-    int W = 0, d = 0;
+    int W = 0, d = 0, E = 1;
+    int threads = 1024;       // workgroup size of the half-step kernel
     unsigned long long seed = 0;
-    alabi::DimVec lo, hi;
-    // drawn randoms for a chunk of steps
-    int chunk_cap = 0;        // steps the buffers hold
-    long long drawn_step0 = -1;
+    double lo[ALABI_MAX_DIM], hi[ALABI_MAX_DIM];
+    double* consts = nullptr; // device [3][ALABI_MAX_DIM]: inv_len, lo, hi
+    long long consts_gen = -1;
+    int chunk_cap = 0;        // steps the draw buffers hold
     int drawn_n = 0;
-    int* order = nullptr;     // [chunk_cap, W]
-    int* partner = nullptr;   // [chunk_cap, W]
-    double* u_z = nullptr;    // [chunk_cap, W]
-    double* u_acc = nullptr;  // [chunk_cap, W]
+    alabi::DrawBuffers draws{};
     // graph cache for the single-GPU run loop
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey {
@@ -88,7 +101,7 @@ struct alabi_ens {
         long long gp_gen;  // generation counter of the GP (re-capture after a refit)
     } graph_key{};
     int graph_steps = 0;
-    long long* run_state = nullptr;  // device [4]: step_base, stored_base
+    long long* run_state = nullptr;  // device [4]: [0] first global step of the chunk, [1] steps done before it
 };
 
 namespace alabi {
@@ -114,23 +127,23 @@ int launch_argmin(const double* u, long long M, double* partial_val, long long* 
                   int nblocks, hipStream_t s);
 // ensemble.hip
 struct HalfArgs {
-    double* coords;              // [W,d] in/out
-    double* logp;                // [W] in/out
-    const int* order;            // [W] set 0 then set 1
-    const double* u_z;           // [W] by walker id
-    const int* partner;          // [W] by walker id
-    const double* u_acc;         // [W] by walker id
+    double* coords;              // [E*W,d] in/out
+    double* logp;                // [E*W] in/out
+    DrawBuffers rec;             // already offset to the step
+    const double* consts;        // device [3][ALABI_MAX_DIM]: inv_len, lo, hi
     const double* Xt;            // [D,Npad]
     const double* alpha;         // [Npad]
-    double* chain;               // [nstore,W,d] or null
-    double* chain_logp;          // [nstore,W] or null
-    long long* n_accept;         // [W] or null
+    double* chain;               // [nstore,E*W,d] or null
+    double* chain_logp;          // [nstore,E*W] or null
+    long long* n_accept;         // [E*W] or null
     const long long* run_state;  // [0] chunk's first global step, [1] steps done before the chunk
     int n0, W, d, Npad, split, part_begin, local_t, thin_by;
-    double a, amp, mean;
+    double amp, mean;
 };
-int launch_ens_draw(alabi_ens* e, int nsteps, hipStream_t s);
+int launch_ens_draw(alabi_ens* e, int nsteps, double a, hipStream_t s);
+int launch_ens_prep(alabi_ens* e, const int* order, int n0, const double* u_z, const int* partner,
+                    const double* u_acc, double a, hipStream_t s);
 int launch_ens_half_args(alabi_ens* e, const HalfArgs& args, int nblocks, hipStream_t s);
-int launch_ens_lnprob(alabi_ens* e, const double* coords, int W, double* logp, hipStream_t s);
+int launch_ens_lnprob(alabi_ens* e, const double* coords, int nwalkers, double* logp, hipStream_t s);
 int launch_ens_advance(alabi_ens* e, long long n, hipStream_t s);
 }  // namespace alabi

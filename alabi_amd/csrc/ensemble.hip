@@ -9,14 +9,20 @@
 //   active set S: z = ((a-1)u+1)^2/a, partner r = randint(|C|), q = C[r] - (C[r]-S_k) z,
 //   accept iff (d-1) ln z + lnp(q) - lnp(S_k) > ln u'.
 //
+// E independent ensembles of W walkers ("independent chains") can share every launch: walker
+// ids are global (e*W + i), lists are per-ensemble segments, blockIdx.y is the ensemble.
+//
 // Kernels
-//   ens_draw_kernel   one workgroup per step: Philox4x32-10 keys -> rank -> label -> the two
-//                     ordered walker lists, plus (u_z, partner, u_acc) per walker.  Draws
-//                     depend only on (seed, step, walker): every rank of a multi-GPU run and
-//                     the CPU oracle generate identical values.
-//   ens_half_kernel   one workgroup per proposal of a half step: the first d lanes build the
-//                     proposal and the box test; then all 256 lanes evaluate the GP mean with
-//                     coalesced SoA loads of the training set and a shuffle+LDS reduction;
+//   ens_draw_kernel   one workgroup per (step, ensemble): Philox4x32-10 keys -> rank -> label ->
+//                     the two ordered walker lists, then per list position one proposal record
+//                     (walker id, partner walker id, z, (d-1) ln z, ln u').  Draws depend only on
+//                     (seed, step, global walker id): every rank of a multi-GPU run and the CPU
+//                     oracle generate identical values.
+//   ens_prep_kernel   the same record construction from caller-supplied draws (test entry).
+//   ens_half_kernel   one workgroup per proposal of a half step.  The record is ONE dependent
+//                     load away from blockIdx (no list -> partner -> list chasing); the first d
+//                     lanes build the proposal and the box test; all lanes evaluate the GP mean
+//                     with coalesced SoA loads of the training set and a shuffle+LDS reduction;
 //                     lane 0 does the accept test; the walker's state (and its chain row) is
 //                     written in place.  Walkers of S write, walkers of C are only read, so a
 //                     half step needs no intra-kernel synchronisation; the two half steps are
@@ -48,21 +54,36 @@ __device__ inline double u53(uint32_t a, uint32_t b) {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
 
-// grid = steps of the chunk; dynamic LDS = W * (8 + 4) bytes.
+// Proposal record of list position `pos` (walker id wid = order[pos]) from raw draws keyed by
+// walker id.  z = ((a-1) u + 1)^2 / a in NumPy's operation order (no contraction).
+__device__ inline void write_record(const DrawBuffers& b, size_t pos, int wid, int cw, double u_z, double u_acc,
+                                    double a, int d) {
+    const double t1 = (a - 1.0) * u_z + 1.0;
+    const double zz = (t1 * t1) / a;
+    b.order[pos] = wid;
+    b.cw[pos] = cw;
+    b.zz[pos] = zz;
+    b.lnfac[pos] = ((double)d - 1.0) * log(zz);
+    b.lnu[pos] = log(u_acc);
+}
+
+// grid = (steps of the chunk, ensembles); dynamic LDS = W * (8 + 4 + 4) bytes.
 __global__ void __launch_bounds__(256)
-ens_draw_kernel(unsigned long long seed, const long long* __restrict__ run_state, int W,
-                int* __restrict__ order, int* __restrict__ partner, double* __restrict__ u_z,
-                double* __restrict__ u_acc) {
+ens_draw_kernel(unsigned long long seed, const long long* __restrict__ run_state, int W, int d, double a,
+                DrawBuffers b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
     int* label = reinterpret_cast<int*>(smem + (size_t)W * 8);
+    int* olist = label + W;   // local ids in list order (set 0 then set 1)
+    const int E = gridDim.y, e = blockIdx.y;
     const long long step = run_state[0] + blockIdx.x;
     const uint32_t s_lo = (uint32_t)step, s_hi = (uint32_t)((unsigned long long)step >> 32);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    const size_t base = (size_t)blockIdx.x * W;
+    const size_t base = ((size_t)blockIdx.x * E + e) * W;
+    const uint32_t g0 = (uint32_t)e * (uint32_t)W;  // global id of this ensemble's walker 0
     uint32_t r[4];
     for (int i = threadIdx.x; i < W; i += 256) {
-        philox4x32_10(s_lo, s_hi, (uint32_t)i, 0u, k0, k1, r);
+        philox4x32_10(s_lo, s_hi, g0 + (uint32_t)i, 0u, k0, k1, r);
         keys[i] = ((uint64_t)r[0] << 32) | r[1];
     }
     __syncthreads();
@@ -81,63 +102,138 @@ ens_draw_kernel(unsigned long long seed, const long long* __restrict__ run_state
         const int li = label[i];
         int pos = 0;
         for (int j = 0; j < i; ++j) pos += (label[j] == li);
-        order[base + (li ? n0 : 0) + pos] = i;
-        philox4x32_10(s_lo, s_hi, (uint32_t)i, 1u, k0, k1, r);
-        u_z[base + i] = u53(r[0], r[1]);
+        olist[(li ? n0 : 0) + pos] = i;
+    }
+    __syncthreads();
+    for (int pos = threadIdx.x; pos < W; pos += 256) {
+        const int i = olist[pos];
+        const int li = pos >= n0;
+        philox4x32_10(s_lo, s_hi, g0 + (uint32_t)i, 1u, k0, k1, r);
+        const double uz = u53(r[0], r[1]);
         const uint64_t nc = li ? (uint64_t)n0 : (uint64_t)(W - n0);
-        partner[base + i] = (int)(((uint64_t)r[2] * nc) >> 32);
-        philox4x32_10(s_lo, s_hi, (uint32_t)i, 2u, k0, k1, r);
-        u_acc[base + i] = u53(r[0], r[1]);
+        const int pr = (int)(((uint64_t)r[2] * nc) >> 32);
+        const int cw = olist[(li ? 0 : n0) + pr];
+        philox4x32_10(s_lo, s_hi, g0 + (uint32_t)i, 2u, k0, k1, r);
+        const double ua = u53(r[0], r[1]);
+        b.partner[base + pos] = pr;
+        b.u_z[base + pos] = uz;
+        b.u_acc[base + pos] = ua;
+        write_record(b, base + pos, (int)g0 + i, (int)g0 + cw, uz, ua, a, d);
     }
 }
 
+// Records from caller-supplied draws (E = 1): order[W] lists set 0 then set 1, u_z / partner / u_acc are
+// keyed by WALKER id, partner indexes the complementary list.  Bad indices yield an inert record (w = -1).
+__global__ void __launch_bounds__(256)
+ens_prep_kernel(const int* __restrict__ order, int n0, int W, const double* __restrict__ u_z,
+                const int* __restrict__ partner, const double* __restrict__ u_acc, double a, int d,
+                DrawBuffers b) {
+    const int pos = blockIdx.x * 256 + threadIdx.x;
+    if (pos >= W) return;
+    const int w = order[pos];
+    const int li = pos >= n0;
+    const int nC = li ? n0 : W - n0;
+    int cw = -1;
+    double uz = 0.5, ua = 0.5;
+    int wid = -1;
+    if ((unsigned)w < (unsigned)W) {
+        const int pr = partner[w];
+        if ((unsigned)pr < (unsigned)nC) {
+            const int c = order[(li ? 0 : n0) + pr];
+            if ((unsigned)c < (unsigned)W) { wid = w; cw = c; uz = u_z[w]; ua = u_acc[w]; }
+        }
+    }
+    write_record(b, pos, wid, cw, uz, ua, a, d);
+}
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 template <int D>
-__global__ void __launch_bounds__(256)
-ens_half_kernel(HalfArgs p, DimVec inv_len, DimVec lo, DimVec hi) {
+__global__ void __launch_bounds__(1024)
+ens_half_kernel(HalfArgs p) {
     __shared__ double q_s[ALABI_MAX_DIM], qs_s[ALABI_MAX_DIM], old_s[ALABI_MAX_DIM];
-    __shared__ double scratch[4];
-    __shared__ int acc_s;
-    const int tid = threadIdx.x;
-    const int* S = p.split == 0 ? p.order : p.order + p.n0;
-    const int* C = p.split == 0 ? p.order + p.n0 : p.order;
-    const int w = S[p.part_begin + blockIdx.x];
-    const int nC = p.split == 0 ? p.W - p.n0 : p.n0;
-    // caller-supplied lists (test entry) are range-checked: a bad index must not become a wild access
-    if ((unsigned)w >= (unsigned)p.W) return;
-    const int pr = p.partner[w];
-    if ((unsigned)pr >= (unsigned)nC) return;
-    const int cw = C[pr];
-    if ((unsigned)cw >= (unsigned)p.W) return;
-    // z = ((a-1) u + 1)^2 / a, evaluated in numpy's operation order (no contraction)
-    const double t1 = (p.a - 1.0) * p.u_z[w] + 1.0;
-    const double zz = (t1 * t1) / p.a;
+    __shared__ double scratch[16];
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int e = blockIdx.y;
+    const size_t pos = (size_t)e * p.W + (p.split ? p.n0 : 0) + p.part_begin + blockIdx.x;
+    // (1) Issue this thread's first training-point loads right away (16 B per lane: points 2*tid and
+    //     2*tid+1 of every coordinate row): they do not depend on the proposal, so their latency -- every
+    //     kernel starts with a cold L2 on this chip, and a CU ingests only ~64 B/clk -- overlaps the
+    //     record -> coords chain below.
+    const int half = p.Npad >> 1;                 // Npad is a multiple of 64
+    const bool vA = tid < half;
+    f64x2 xa[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        xa[k] = vA ? reinterpret_cast<const f64x2*>(p.Xt + (size_t)k * p.Npad)[tid] : f64x2{0.0, 0.0};
+    const f64x2 aa = vA ? reinterpret_cast<const f64x2*>(p.alpha)[tid] : f64x2{0.0, 0.0};
+    // (2) proposal record: one dependent load away from blockIdx
+    const int w = p.rec.order[pos];
+    if (w < 0) return;  // inert record (range-checked test input); workgroup-uniform
+    const int cw = p.rec.cw[pos];
+    const double zz = p.rec.zz[pos];
+    double lp_old = 0.0, lnfac = 0.0, lnu = 0.0;
+    if (tid < 64) { lp_old = p.logp[w]; lnfac = p.rec.lnfac[pos]; lnu = p.rec.lnu[pos]; }  // wave 0 decides
+    const double* inv_len = p.consts;
+    const double* lo = p.consts + ALABI_MAX_DIM;
+    const double* hi = p.consts + 2 * ALABI_MAX_DIM;
     int ok = 1;
     if (tid < D) {
-        double qv = 0.0, sv = 0.0;
+        double qv = 0.0;
         if (tid < p.d) {
             const double cv = p.coords[(size_t)cw * p.d + tid];
-            sv = p.coords[(size_t)w * p.d + tid];
+            const double sv = p.coords[(size_t)w * p.d + tid];
             qv = cv - (cv - sv) * zz;
-            ok = (qv > lo.v[tid]) && (qv < hi.v[tid]);
+            ok = (qv > lo[tid]) && (qv < hi[tid]);
             q_s[tid] = qv; old_s[tid] = sv;
+            qv *= inv_len[tid];
         }
-        qs_s[tid] = (tid < p.d) ? qv * inv_len.v[tid] : 0.0;
+        qs_s[tid] = qv;
     }
     const int inb = __syncthreads_and(ok);
     double lp_new = -INFINITY;
     if (inb) {  // workgroup-uniform
-        const double s = gp_kernel_dot_block<D>(p.Xt, p.alpha, p.Npad, qs_s, scratch);
+        double q[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) q[k] = qs_s[k];
+        double r2a = 0.0, r2b = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const double da = xa[k].x - q[k], db = xa[k].y - q[k];
+            r2a = fma(da, da, r2a);
+            r2b = fma(db, db, r2b);
+        }
+        double acc = aa.x * exp(-0.5 * r2a);
+        acc = fma(aa.y, exp(-0.5 * r2b), acc);
+        for (int j = tid + T; j < half; j += T) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const f64x2 x = reinterpret_cast<const f64x2*>(p.Xt + (size_t)k * p.Npad)[j];
+                const double d0 = x.x - q[k], d1 = x.y - q[k];
+                s0 = fma(d0, d0, s0);
+                s1 = fma(d1, d1, s1);
+            }
+            const f64x2 al = reinterpret_cast<const f64x2*>(p.alpha)[j];
+            acc = fma(al.x, exp(-0.5 * s0), acc);
+            acc = fma(al.y, exp(-0.5 * s1), acc);
+        }
+        // (3) wave totals by DPP, one LDS word per wave, ONE barrier; only wave 0 goes on
+        const double wsum = wave_sum_dpp(acc);
+        if ((tid & 63) == 63) scratch[tid >> 6] = wsum;
+        __syncthreads();
+        if (tid >= 64) return;
+        const int nw = T >> 6;
+        double part = (tid < nw) ? scratch[tid] : 0.0;
+        part = wave_sum_dpp(part);   // fixed order: bit-reproducible
+        const double s = lane_bcast(part, 63);
         lp_new = fma(p.amp, s, p.mean);
+    } else if (tid >= 64) {
+        return;
     }
-    const double lp_old = p.logp[w];
-    if (tid == 0) {
-        const double lnpdiff = ((double)p.d - 1.0) * log(zz) + lp_new - lp_old;
-        acc_s = (lnpdiff > log(p.u_acc[w])) ? 1 : 0;
-    }
-    __syncthreads();
-    const int acc = acc_s;
-    if (acc) {
+    // (4) wave 0: accept test in every lane (same inputs), first d lanes write the state
+    const int acc_flag = (lnfac + lp_new - lp_old > lnu) ? 1 : 0;
+    if (acc_flag) {
         if (tid < p.d) p.coords[(size_t)w * p.d + tid] = q_s[tid];
         if (tid == 0) {
             p.logp[w] = lp_new;
@@ -147,29 +243,33 @@ ens_half_kernel(HalfArgs p, DimVec inv_len, DimVec lo, DimVec hi) {
     if (p.chain || p.chain_logp) {
         const long long done = p.run_state[1] + p.local_t + 1;
         if (done % p.thin_by == 0) {
-            const long long slot = done / p.thin_by - 1;
-            if (p.chain && tid < p.d) p.chain[((size_t)slot * p.W + w) * p.d + tid] = acc ? q_s[tid] : old_s[tid];
-            if (p.chain_logp && tid == 0) p.chain_logp[(size_t)slot * p.W + w] = acc ? lp_new : lp_old;
+            const size_t slot = (size_t)(done / p.thin_by - 1);
+            const size_t WT = (size_t)p.W * gridDim.y;
+            if (p.chain && tid < p.d)
+                __builtin_nontemporal_store(acc_flag ? q_s[tid] : old_s[tid], &p.chain[(slot * WT + w) * p.d + tid]);
+            if (p.chain_logp && tid == 0)
+                __builtin_nontemporal_store(acc_flag ? lp_new : lp_old, &p.chain_logp[slot * WT + w]);
         }
     }
 }
 
 template <int D>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 ens_lnprob_kernel(const double* __restrict__ coords, int d, const double* __restrict__ Xt,
-                  const double* __restrict__ alpha, int Npad, double amp, double mean, DimVec inv_len,
-                  DimVec lo, DimVec hi, double* __restrict__ logp) {
+                  const double* __restrict__ alpha, int Npad, double amp, double mean,
+                  const double* __restrict__ consts, double* __restrict__ logp) {
     __shared__ double qs_s[ALABI_MAX_DIM];
-    __shared__ double scratch[4];
+    __shared__ double scratch[16];
     const int tid = threadIdx.x, w = blockIdx.x;
     int ok = 1;
     if (tid < D) {
         double qv = 0.0;
         if (tid < d) {
             qv = coords[(size_t)w * d + tid];
-            ok = (qv > lo.v[tid]) && (qv < hi.v[tid]);
+            ok = (qv > consts[ALABI_MAX_DIM + tid]) && (qv < consts[2 * ALABI_MAX_DIM + tid]);
+            qv *= consts[tid];
         }
-        qs_s[tid] = qv * ((tid < d) ? inv_len.v[tid] : 0.0);
+        qs_s[tid] = qv;
     }
     const int inb = __syncthreads_and(ok);
     double lp = -INFINITY;
@@ -181,10 +281,18 @@ __global__ void ens_advance_kernel(long long* run_state, long long n) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { run_state[0] += n; run_state[1] += n; }
 }
 
-int launch_ens_draw(alabi_ens* e, int nsteps, hipStream_t s) {
-    const size_t lds = (size_t)e->W * 12;
-    hipLaunchKernelGGL(ens_draw_kernel, dim3(nsteps), dim3(256), lds, s, e->seed, e->run_state, e->W, e->order,
-                       e->partner, e->u_z, e->u_acc);
+int launch_ens_draw(alabi_ens* e, int nsteps, double a, hipStream_t s) {
+    const size_t lds = (size_t)e->W * 16;
+    hipLaunchKernelGGL(ens_draw_kernel, dim3(nsteps, e->E), dim3(256), lds, s, e->seed, e->run_state, e->W, e->d, a,
+                       e->draws);
+    ALABI_LAUNCH_CHECK();
+    return ALABI_OK;
+}
+
+int launch_ens_prep(alabi_ens* e, const int* order, int n0, const double* u_z, const int* partner,
+                    const double* u_acc, double a, hipStream_t s) {
+    hipLaunchKernelGGL(ens_prep_kernel, dim3((e->W + 255) / 256), dim3(256), 0, s, order, n0, e->W, u_z, partner, u_acc,
+                       a, e->d, e->draws);
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }
@@ -192,18 +300,18 @@ int launch_ens_draw(alabi_ens* e, int nsteps, hipStream_t s) {
 int launch_ens_half_args(alabi_ens* e, const HalfArgs& args, int nblocks, hipStream_t s) {
     if (nblocks <= 0) return ALABI_OK;
     const int db = dim_bucket(e->d);
-    ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(ens_half_kernel<D>, dim3(nblocks), dim3(256), 0, s, args,
-                                              e->gp->inv_len, e->lo, e->hi));
+    const int threads = e->threads;
+    ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(ens_half_kernel<D>, dim3(nblocks, e->E), dim3(threads), 0, s, args));
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }
 
-int launch_ens_lnprob(alabi_ens* e, const double* coords, int W, double* logp, hipStream_t s) {
+int launch_ens_lnprob(alabi_ens* e, const double* coords, int nwalkers, double* logp, hipStream_t s) {
     const int db = dim_bucket(e->d);
     alabi_gp* gp = e->gp;
-    ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(ens_lnprob_kernel<D>, dim3(W), dim3(256), 0, s, coords, e->d, gp->Xt,
-                                              gp->alpha, gp->Npad, exp(gp->log_amp), gp->mean, gp->inv_len,
-                                              e->lo, e->hi, logp));
+    ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(ens_lnprob_kernel<D>, dim3(nwalkers), dim3(e->threads), 0, s, coords, e->d,
+                                              gp->Xt, gp->alpha, gp->Npad, exp(gp->log_amp), gp->mean, e->consts,
+                                              logp));
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

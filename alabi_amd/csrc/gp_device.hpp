@@ -40,15 +40,45 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
-// Sum over a 256-thread workgroup in a fixed order; `scratch` is >= 4 doubles of LDS.
-// Every thread returns the total.
-__device__ inline double block_sum_256(double v, double* scratch) {
+// One DPP data move of a double (two 32-bit halves); lanes without a source read 0.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Wave-wide sum with DPP (no LDS round trips): row_shr 1,2,4,8 build the 16-lane row totals in lanes
+// 15/31/47/63, row_bcast:15 and row_bcast:31 fold the rows; the total ends in lane 63.  The order of
+// the additions is fixed, so the result is reproducible.  ~6 x (2 v_mov_dpp + v_add_f64).
+__device__ inline double wave_sum_dpp(double v) {
+    v += dpp_move<0x111, 0xf>(v);   // row_shr:1
+    v += dpp_move<0x112, 0xf>(v);   // row_shr:2
+    v += dpp_move<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_move<0x118, 0xf>(v);   // row_shr:8
+    v += dpp_move<0x142, 0xa>(v);   // row_bcast:15 -> rows 1 and 3
+    v += dpp_move<0x143, 0xc>(v);   // row_bcast:31 -> rows 2 and 3
+    return v;                       // valid in lane 63
+}
+
+__device__ inline double lane_bcast(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the workgroup (any multiple of 64 threads up to 1024) in a fixed order; `scratch` is >= 16
+// doubles of LDS.  Every thread returns the total.
+__device__ inline double block_sum(double v, double* scratch) {
     v = wave_sum(v);
-    const int w = threadIdx.x >> 6;
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();  // scratch may still be read from a previous call
     if ((threadIdx.x & 63) == 0) scratch[w] = v;
     __syncthreads();
-    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    double t = scratch[0];
+    for (int k = 1; k < nw; ++k) t += scratch[k];
+    return t;
 }
 
 // sum_n alpha[n] * exp(-0.5 * |Xt[:,n] - q|^2) over all (padded) training points, one
@@ -61,7 +91,7 @@ __device__ inline double gp_kernel_dot_block(const double* __restrict__ Xt, cons
 #pragma unroll
     for (int k = 0; k < D; ++k) q[k] = q_lds[k];
     double acc = 0.0;
-    for (int n = threadIdx.x; n < Npad; n += 256) {
+    for (int n = threadIdx.x; n < Npad; n += blockDim.x) {
         double r2 = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
@@ -70,7 +100,7 @@ __device__ inline double gp_kernel_dot_block(const double* __restrict__ Xt, cons
         }
         acc = fma(alpha[n], exp(-0.5 * r2), acc);
     }
-    return block_sum_256(acc, scratch);
+    return block_sum(acc, scratch);
 }
 
 }  // namespace alabi

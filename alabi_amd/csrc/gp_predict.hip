@@ -31,7 +31,7 @@ predict_mean_rowwise_kernel(const double* __restrict__ Xt, const double* __restr
                             const double* __restrict__ Xs, int d, DimVec inv_len, double amp, double mean,
                             double* __restrict__ mu) {
     __shared__ double q[ALABI_MAX_DIM];
-    __shared__ double scratch[4];
+    __shared__ double scratch[16];
     const long long m = blockIdx.x;
     if (threadIdx.x < D) q[threadIdx.x] = (threadIdx.x < d) ? Xs[m * d + threadIdx.x] * inv_len.v[threadIdx.x] : 0.0;
     __syncthreads();

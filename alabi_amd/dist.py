@@ -49,8 +49,8 @@ class HipBackend:
     def lnprob(self, coords):
         return self.s.compute_log_prob(coords)
 
-    def draw(self, step0, n):
-        _lib.check(_lib.lib().alabi_ens_draw(self.s._ens, int(step0), int(n), _lib.current_stream()), "alabi_ens_draw")
+    def draw(self, step0, n, a):
+        _lib.check(_lib.lib().alabi_ens_draw(self.s._ens, int(step0), int(n), float(a), _lib.current_stream()), "alabi_ens_draw")
 
     def order(self, t):
         out = torch.empty(self.W, dtype=torch.int32, device=self.device)
@@ -61,7 +61,7 @@ class HipBackend:
 
     def half_step(self, coords, logp, t, split, begin, end, a, n_accept):
         st = _lib.lib().alabi_ens_half_step(self.s._ens, _lib.ptr(coords), _lib.ptr(logp), int(t), int(split), int(begin),
-                                            int(end), float(a), _lib.ptr(n_accept), _lib.current_stream())
+                                            int(end), _lib.ptr(n_accept), _lib.current_stream())
         _lib.check(st, "alabi_ens_half_step")
 
 
@@ -105,7 +105,7 @@ class ShardedEnsemble:
         done = 0
         while done < nsteps:
             n = min(self.b.chunk, nsteps - done)
-            self.b.draw(step0 + done, n)
+            self.b.draw(step0 + done, n, a)
             for t in range(n):
                 order, n0 = self.b.order(t)
                 for split in (0, 1):

@@ -37,10 +37,15 @@ class State:
 
 
 class EnsembleSampler:
-    def __init__(self, nwalkers, ndim, gp, y, bounds, seed=None, a=2.0, pool=None, live_dangerously=False, **unused):
+    def __init__(self, nwalkers, ndim, gp, y, bounds, seed=None, a=2.0, pool=None, live_dangerously=False,
+                 n_ensembles=1, **unused):
+        """``n_ensembles`` > 1 runs that many INDEPENDENT ensembles of ``nwalkers`` walkers in the same kernel
+        launches (rows [e*nwalkers, (e+1)*nwalkers) of every array belong to ensemble e)."""
         if not isinstance(gp, HipGP):
             raise TypeError("EnsembleSampler needs the HipGP surrogate (the log-probability is fused into the kernel)")
         self.nwalkers = int(nwalkers)
+        self.n_ensembles = int(n_ensembles)
+        self.total_walkers = self.nwalkers * self.n_ensembles
         self.ndim = int(ndim)
         if self.ndim != gp.ndim:
             raise ValueError("ndim does not match the GP")
@@ -60,7 +65,7 @@ class EnsembleSampler:
         self._chains = []
         self._chain_lps = []
         self._thins = []
-        self._naccept = torch.zeros(self.nwalkers, dtype=torch.int64, device=_dev())
+        self._naccept = torch.zeros(self.total_walkers, dtype=torch.int64, device=_dev())
         self._stream = torch.cuda.Stream()
         self._ens = None
         self._ens_gp_handle = None
@@ -74,8 +79,8 @@ class EnsembleSampler:
             return
         self._release()
         e = C.c_void_p()
-        st = _lib.lib().alabi_ens_create(h, self.nwalkers, self.ndim, _lib.host_doubles(self.bounds.ravel()),
-                                         C.c_ulonglong(self.seed), C.byref(e))
+        st = _lib.lib().alabi_ens_create(h, self.nwalkers, self.ndim, self.n_ensembles,
+                                         _lib.host_doubles(self.bounds.ravel()), C.c_ulonglong(self.seed), C.byref(e))
         _lib.check(st, "alabi_ens_create")
         self._ens = e
         self._ens_gp_handle = C.c_void_p(h.value)
@@ -117,9 +122,9 @@ class EnsembleSampler:
         """Surrogate mean + box prior for an ensemble of points (device in, device out)."""
         self._ensure_ens()
         c = _to_dev(coords, 2)
-        if c.shape != (self.nwalkers, self.ndim):
-            raise ValueError("coords must have shape (nwalkers, ndim)")
-        lp = torch.empty(self.nwalkers, dtype=torch.float64, device=c.device)
+        if c.shape != (self.total_walkers, self.ndim):
+            raise ValueError("coords must have shape (nwalkers * n_ensembles, ndim)")
+        lp = torch.empty(self.total_walkers, dtype=torch.float64, device=c.device)
         _lib.check(_lib.lib().alabi_ens_lnprob(self._ens, _lib.ptr(c), _lib.ptr(lp), _lib.current_stream()), "alabi_ens_lnprob")
         return lp
 
@@ -134,8 +139,8 @@ class EnsembleSampler:
         else:
             coords = initial_state.coords if isinstance(initial_state, State) else initial_state
             coords = _to_dev(coords, 2).clone()
-            if coords.shape != (self.nwalkers, self.ndim):
-                raise ValueError("incompatible input dimensions: initial state must be (nwalkers, ndim)")
+            if coords.shape != (self.total_walkers, self.ndim):
+                raise ValueError("incompatible input dimensions: initial state must be (nwalkers * n_ensembles, ndim)")
             if not skip_initial_state_check and self.nwalkers > 1:
                 c = coords.cpu().numpy()
                 c = c - c.mean(axis=0)
@@ -153,8 +158,8 @@ class EnsembleSampler:
         self._ensure_ens()
         nstore = nsteps // thin_by if store else 0
         dev = self._coords.device
-        chain = torch.empty((nstore, self.nwalkers, self.ndim), dtype=torch.float64, device=dev) if nstore else None
-        chain_lp = torch.empty((nstore, self.nwalkers), dtype=torch.float64, device=dev) if nstore else None
+        chain = torch.empty((nstore, self.total_walkers, self.ndim), dtype=torch.float64, device=dev) if nstore else None
+        chain_lp = torch.empty((nstore, self.total_walkers), dtype=torch.float64, device=dev) if nstore else None
         t0 = time.perf_counter()
         self._stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._stream):

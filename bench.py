@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--walkers", type=int, default=None)
     ap.add_argument("--ntrain", type=int, default=None)
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas")
+    ap.add_argument("--ensembles", type=int, default=1,
+                    help="independent ensembles of --walkers walkers sharing every launch on each GPU (default 1 = the "
+                         "headline configuration: ONE 256-walker ensemble per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the predict / Cholesky side measurements")
     args = ap.parse_args()
@@ -117,13 +120,16 @@ def main():
         samples_per_step = Wtot * args.mcmc_steps
         launches_per_step = 2 * args.mcmc_steps
     else:
-        sampler = EnsembleSampler(W, d, gp, cfg["y"], cfg["bounds"], seed=2026 + rank)
-        sampler.run_mcmc(cfg["p0"], 1, store=False)
+        E = args.ensembles
+        sampler = EnsembleSampler(W, d, gp, cfg["y"], cfg["bounds"], seed=2026 + rank, n_ensembles=E)
+        p0 = cfg["p0"] if E == 1 else np.random.RandomState(77).uniform(
+            cfg["bounds"][:, 0] * 0.5, cfg["bounds"][:, 1] * 0.5, (W * E, d))
+        sampler.run_mcmc(p0, 1, store=False)
 
         def one_step():
             sampler.run_mcmc(None, args.mcmc_steps, store=True)
             sampler._chains.clear(); sampler._chain_lps.clear(); sampler._thins.clear()
-        samples_per_step = W * args.mcmc_steps * world
+        samples_per_step = W * E * args.mcmc_steps * world
         launches_per_step = 2 * args.mcmc_steps
 
     def fence():
@@ -156,14 +162,15 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{cfg['name']}: {cfg['description']}", "N_train": N, "d": d,
-                   "walkers_per_gpu": W, "mcmc_steps_per_bench_step": args.mcmc_steps,
+                   "walkers_per_gpu": W * (1 if shard else args.ensembles), "ensembles_per_gpu": 1 if shard else args.ensembles,
+                   "mcmc_steps_per_bench_step": args.mcmc_steps,
                    "parallelism": ("sharded-ensemble+allgather" if shard else "replicas") if world > 1 else "single-gpu",
                    "chain_stored": True},
     }
     if rank == 0:
         # dominant kernel = ens_half_kernel (2 launches per stretch-move step).  Algorithmic flops per launch:
         # (W/2) proposals x N training points x (2d + 2 flops + 1 exp counted as 1 flop).
-        n_prop = (W * world if shard else W) / 2.0 / (world if shard else 1)
+        n_prop = (W * world if shard else W * args.ensembles) / 2.0 / (world if shard else 1)
         flops_per_launch = n_prop * N * (2 * d + 3)
         us_per_launch = 1e3 * ev_ms / (args.steps * launches_per_step)
         achieved = flops_per_launch / (us_per_launch * 1e-6) / 1e12

@@ -102,47 +102,50 @@ int alabi_utility_eval(int algo, const double* Xs, long long M, int d, const dou
 
 /* Ensemble sampler: replaces emcee.EnsembleSampler(W, d, sm.lnprob).run_mcmc(p0, nsteps)
  * with the StretchMove -- alabi/core.py:2319-2325, lnprob = surrogate mean + box prior
- * (alabi/core.py:2073-2100, utility.py:218-275).  Walkers [first_walker, first_walker +
- * n_local) are the ones THIS rank proposes for (multi-GPU sharding); a single-GPU run
- * passes 0, W.  bounds is a host array [d,2] in the GP's (scaled) coordinates. */
-int alabi_ens_create(alabi_gp* gp, int W, int d, const double* bounds,
+ * (alabi/core.py:2073-2100, utility.py:218-275).  n_ensembles >= 1 independent ensembles of
+ * W walkers each ("independent chains") share every launch; walker ids are global
+ * (ensemble e owns rows [e*W, (e+1)*W) of coords / logp / chain) and walkers only interact
+ * inside their ensemble.  bounds is a host array [d,2] in the GP's (scaled) coordinates. */
+int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* bounds,
                      unsigned long long seed, alabi_ens** out);
 int alabi_ens_destroy(alabi_ens* ens);
 
-/* log-probability of an ensemble of points (surrogate mean + box prior). */
-int alabi_ens_lnprob(alabi_ens* ens, const double* coords /* [W,d] */, double* logp /* [W] */,
-                     void* stream);
+/* log-probability of every walker (surrogate mean + box prior): coords [E*W,d] -> logp [E*W]. */
+int alabi_ens_lnprob(alabi_ens* ens, const double* coords, double* logp, void* stream);
 
-/* Run nsteps full stretch-move steps on one GPU.  coords [W,d] and logp [W] are updated in
- * place; chain [nsteps/thin_by, W, d] and chain_logp [nsteps/thin_by, W] receive every
- * thin_by-th state (either may be NULL); n_accept [W] int64 is ADDED to.  step0 is the
- * global index of the first step (counter-based RNG: draws depend on (seed, step, walker)
- * only).  Enqueues on `stream`; does not synchronise. */
+/* Run nsteps full stretch-move steps on one GPU.  coords [E*W,d] and logp [E*W] are updated in
+ * place; chain [nsteps/thin_by, E*W, d] and chain_logp [nsteps/thin_by, E*W] receive every
+ * thin_by-th state (either may be NULL); n_accept [E*W] int64 is ADDED to.  step0 is the
+ * global index of the first step (counter-based RNG: draws depend on (seed, step, global
+ * walker id) only).  Enqueues on `stream`; does not synchronise with the kernels. */
 int alabi_ens_run(alabi_ens* ens, double* coords, double* logp, long long step0,
                   long long nsteps, int thin_by, double a, double* chain, double* chain_logp,
                   long long* n_accept, void* stream);
 
-/* Multi-GPU building blocks (alabi_amd/dist.py drives them around an RCCL all-gather):
- * draw the randoms of steps [step0, step0+nsteps) into the handle, then apply one HALF
- * step (split 0 or 1 of local step `t`) to the walkers whose position in that half's list
- * lies in [part_begin, part_end). */
-int alabi_ens_draw(alabi_ens* ens, long long step0, int nsteps, void* stream);
+/* Multi-GPU building blocks for ONE sharded ensemble (n_ensembles == 1; alabi_amd/dist.py
+ * drives them around an RCCL all-gather): draw the proposal records of steps
+ * [step0, step0+nsteps) into the handle, then apply one HALF step (split 0 or 1 of local
+ * step `t`) to the walkers whose position in that half's list lies in [part_begin, part_end). */
+int alabi_ens_draw(alabi_ens* ens, long long step0, int nsteps, double a, void* stream);
 int alabi_ens_half_step(alabi_ens* ens, double* coords, double* logp, int t, int split,
-                        int part_begin, int part_end, double a, long long* n_accept,
-                        void* stream);
+                        int part_begin, int part_end, long long* n_accept, void* stream);
 /* copy of the walker lists of drawn local step t: order_out[W] int32 (device), n0 (host). */
 int alabi_ens_step_lists(alabi_ens* ens, int t, int* order_out, int* n0, void* stream);
 
-/* Test entry: one full step from caller-supplied draws keyed by walker id (bit-exact
- * index-arithmetic fixtures).  order[W] int32 lists set 0 then set 1; partner[W] int32
- * indexes the complementary list. */
+/* Test entry (n_ensembles == 1): one full step from caller-supplied draws keyed by WALKER id
+ * (bit-exact index-arithmetic fixtures).  order[W] int32 lists set 0 then set 1; partner[W]
+ * int32 indexes the complementary list.  Out-of-range indices make that proposal a no-op. */
 int alabi_ens_step_with_randoms(alabi_ens* ens, double* coords, double* logp,
                                 const int* order, int n0, const double* u_z,
                                 const int* partner, const double* u_acc, double a,
                                 long long* n_accept, void* stream);
-/* Test entry: the device's counter-based draws for one step, copied out. */
-int alabi_ens_export_draws(alabi_ens* ens, long long step, int* order /* [W] */, int* n0 /* host */,
-                           double* u_z, int* partner, double* u_acc, void* stream);
+/* Test entry: the device's counter-based draws for one step, copied out in LIST order
+ * (position p of ensemble e at [e*W + p]): order = global walker id, partner = index drawn
+ * into the complementary list, u_z / u_acc raw uniforms, cw (nullable) = partner's global
+ * walker id, zz (nullable) = stretch factor.  n0 is a host int. */
+int alabi_ens_export_draws(alabi_ens* ens, long long step, double a, int* order, int* n0,
+                           double* u_z, int* partner, double* u_acc, int* cw, double* zz,
+                           void* stream);
 
 #ifdef __cplusplus
 }

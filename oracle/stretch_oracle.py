@@ -77,8 +77,11 @@ def _ctr(step, walkers, stream):
     return ctr
 
 
-def draw_step_randoms(seed, step, W):
+def draw_step_randoms(seed, step, W, id0=0):
     """Counter-based draws for one step; identical on every rank and on the device.
+
+    ``id0`` is the global id of this ensemble's walker 0 (e * W for the e-th of several independent
+    ensembles sharing a launch); the returned ids stay LOCAL (0..W-1).
 
     Returns (order[W] int32, n0, u_z[W], partner[W] int32, u_acc[W]).
     ``order`` lists the label-0 walkers in index order then the label-1 walkers in
@@ -89,18 +92,19 @@ def draw_step_randoms(seed, step, W):
     """
     key = (int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
     ids = np.arange(W)
-    r = philox4x32_10(_ctr(step, ids, STREAM_SPLIT), key).astype(np.uint64)
+    gids = ids + int(id0)
+    r = philox4x32_10(_ctr(step, gids, STREAM_SPLIT), key).astype(np.uint64)
     k64 = (r[:, 0] << _S32) | r[:, 1]
     rank = np.empty(W, dtype=np.int64)
     rank[np.lexsort((ids, k64))] = ids  # ties broken by walker id
     label = rank % 2
     order = np.concatenate([ids[label == 0], ids[label == 1]]).astype(np.int32)
     n0 = int(np.sum(label == 0))
-    rp = philox4x32_10(_ctr(step, ids, STREAM_PROPOSE), key)
+    rp = philox4x32_10(_ctr(step, gids, STREAM_PROPOSE), key)
     u_z = u53(rp[:, 0], rp[:, 1])
     nc = np.where(label == 0, W - n0, n0).astype(np.uint64)
     partner = ((rp[:, 2].astype(np.uint64) * nc) >> _S32).astype(np.int32)
-    ra = philox4x32_10(_ctr(step, ids, STREAM_ACCEPT), key)
+    ra = philox4x32_10(_ctr(step, gids, STREAM_ACCEPT), key)
     u_acc = u53(ra[:, 0], ra[:, 1])
     return order, n0, u_z, partner, u_acc
 
@@ -204,7 +208,7 @@ def literal_draws_to_arrays(record):
     return order, n0, u_z, partner, u_acc
 
 
-def run_ensemble(p0, nsteps, lnprob_batch, seed, a=2.0, thin_by=1, step0=0, logp0=None):
+def run_ensemble(p0, nsteps, lnprob_batch, seed, a=2.0, thin_by=1, step0=0, logp0=None, id0=0):
     """Array-driven ensemble run with the counter-based draws (device production contract).
 
     Returns chain[nsteps//thin_by, W, d], chain_logp[.., W], n_accept[W], coords, logp.
@@ -217,7 +221,7 @@ def run_ensemble(p0, nsteps, lnprob_batch, seed, a=2.0, thin_by=1, step0=0, logp
     chain_lp = np.empty((nstore, W))
     nacc = np.zeros(W, dtype=np.int64)
     for t in range(nsteps):
-        order, n0, u_z, partner, u_acc = draw_step_randoms(seed, step0 + t, W)
+        order, n0, u_z, partner, u_acc = draw_step_randoms(seed, step0 + t, W, id0)
         coords, logp, acc = stretch_step_arrays(coords, logp, order, n0, u_z, partner, u_acc, lnprob_batch, a)
         nacc += acc
         if (t + 1) % thin_by == 0:

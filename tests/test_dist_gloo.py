@@ -27,7 +27,7 @@ class OracleBackend:
     def lnprob(self, coords):
         return torch.as_tensor(self.lnp(coords.numpy()))
 
-    def draw(self, step0, n):
+    def draw(self, step0, n, a):
         self._draws = [self.so.draw_step_randoms(self.seed, step0 + t, self.W) for t in range(n)]
 
     def order(self, t):

@@ -40,23 +40,34 @@ def test_device_draws_match_oracle_bit_for_bit(setup):
     torch, g, o, y, bounds = setup
     from alabi_amd import EnsembleSampler, _lib
     from oracle.stretch_oracle import draw_step_randoms
-    for W in (10, 64, 257, 1024):
-        s = EnsembleSampler(W, 5, g, y, bounds, seed=0xDEADBEEFCAFE1234, live_dangerously=True)
+    seed = 0xDEADBEEFCAFE1234
+    for W, E in ((10, 1), (64, 1), (257, 1), (1024, 1), (32, 3)):
+        s = EnsembleSampler(W, 5, g, y, bounds, seed=seed, live_dangerously=True, n_ensembles=E)
         s._ensure_ens()
+        WT = W * E
         for step in (0, 1, 12345678901):
-            order = torch.empty(W, dtype=torch.int32, device="cuda"); partner = torch.empty_like(order)
-            u_z = torch.empty(W, dtype=torch.float64, device="cuda"); u_acc = torch.empty_like(u_z)
+            order = torch.empty(WT, dtype=torch.int32, device="cuda"); partner = torch.empty_like(order)
+            cw = torch.empty_like(order)
+            u_z = torch.empty(WT, dtype=torch.float64, device="cuda"); u_acc = torch.empty_like(u_z)
+            zz = torch.empty_like(u_z)
             n0 = C.c_int(0)
-            st = _lib.lib().alabi_ens_export_draws(s._ens, step, _lib.ptr(order), C.byref(n0), _lib.ptr(u_z),
-                                                   _lib.ptr(partner), _lib.ptr(u_acc), _lib.current_stream())
+            st = _lib.lib().alabi_ens_export_draws(s._ens, step, 2.0, _lib.ptr(order), C.byref(n0), _lib.ptr(u_z),
+                                                   _lib.ptr(partner), _lib.ptr(u_acc), _lib.ptr(cw), _lib.ptr(zz),
+                                                   _lib.current_stream())
             _lib.check(st, "export")
             torch.cuda.synchronize()
-            ro, rn0, ruz, rp, rua = draw_step_randoms(0xDEADBEEFCAFE1234, step, W)
-            assert n0.value == rn0
-            assert np.array_equal(order.cpu().numpy(), ro)          # integer index arithmetic: bit exact
-            assert np.array_equal(partner.cpu().numpy(), rp)
-            assert np.array_equal(u_z.cpu().numpy(), ruz)            # 53-bit uniforms: bit exact
-            assert np.array_equal(u_acc.cpu().numpy(), rua)
+            for e in range(E):      # the device exports in LIST order with global ids; the oracle keys by walker id
+                ro, rn0, ruz, rp, rua = draw_step_randoms(seed, step, W, id0=e * W)
+                sl = slice(e * W, (e + 1) * W)
+                assert n0.value == rn0
+                assert np.array_equal(order.cpu().numpy()[sl], ro + e * W)   # integer index arithmetic: bit exact
+                assert np.array_equal(partner.cpu().numpy()[sl], rp[ro])
+                assert np.array_equal(u_z.cpu().numpy()[sl], ruz[ro])        # 53-bit uniforms: bit exact
+                assert np.array_equal(u_acc.cpu().numpy()[sl], rua[ro])
+                ref_cw = np.where(np.arange(W) < rn0, ro[rn0:][np.minimum(rp[ro], W - rn0 - 1)],
+                                  ro[:rn0][np.minimum(rp[ro], rn0 - 1)])
+                assert np.array_equal(cw.cpu().numpy()[sl], ref_cw + e * W)
+                assert np.array_equal(zz.cpu().numpy()[sl], ((2.0 - 1.0) * ruz[ro] + 1.0) ** 2.0 / 2.0)
 
 
 def test_step_with_injected_randoms(setup):
@@ -152,3 +163,23 @@ def test_sampler_statistics_on_gaussian_surrogate(setup):
     tau = s.get_autocorr_time(tol=0)
     assert tau.shape == (5,) and np.all(np.isfinite(tau))
     assert np.all(flat > -3.0) and np.all(flat < 3.0)      # the box prior is never violated
+
+
+def test_independent_ensembles_share_launches(setup):
+    """n_ensembles=E: rows [eW,(e+1)W) evolve exactly like a stand-alone ensemble whose walker ids start at eW."""
+    torch, g, o, y, bounds = setup
+    from alabi_amd import EnsembleSampler
+    from oracle import stretch_oracle as so
+    W, E, nsteps = 24, 4, 150
+    p0 = np.random.RandomState(21).uniform(-2, 2, (W * E, 5))
+    s = EnsembleSampler(W, 5, g, y, bounds, seed=1234, n_ensembles=E)
+    s.run_mcmc(p0, nsteps)
+    chain = s.get_chain()
+    assert chain.shape == (nsteps, W * E, 5)
+    lnp = _lnp(o, y, bounds)
+    for e in range(E):
+        ref, _, nacc, _, _ = so.run_ensemble(p0[e * W:(e + 1) * W], nsteps, lnp, seed=1234, id0=e * W)
+        assert np.max(np.abs(chain[:, e * W:(e + 1) * W] - ref)) < 1e-7
+        assert np.array_equal(s._naccept.cpu().numpy()[e * W:(e + 1) * W], nacc)
+    # ensembles are independent: different draws, different chains
+    assert not np.allclose(chain[-1, :W], chain[-1, W:2 * W])
