@@ -68,6 +68,7 @@ int alabi_gp_create(int n_cap, int d, alabi_gp** out) {
     if (e == hipSuccess) e = hipMalloc(&gp->Xt, (size_t)dim_bucket(d) * nc * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&gp->y, nc * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&gp->alpha, nc * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&gp->dinv, nc * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&gp->work, 2 * nc * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&gp->red, 4 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&gp->info, sizeof(int));
@@ -85,6 +86,7 @@ int alabi_gp_destroy(alabi_gp* gp) {
     if (gp->Xt) (void)hipFree(gp->Xt);
     if (gp->y) (void)hipFree(gp->y);
     if (gp->alpha) (void)hipFree(gp->alpha);
+    if (gp->dinv) (void)hipFree(gp->dinv);
     if (gp->work) (void)hipFree(gp->work);
     if (gp->red) (void)hipFree(gp->red);
     if (gp->info) (void)hipFree(gp->info);

@@ -57,6 +57,7 @@ struct alabi_gp {
     double* Xt = nullptr;     // [d, n_cap]  scaled, transposed training inputs (SoA)
     double* y = nullptr;      // [n_cap]
     double* alpha = nullptr;  // [n_cap]
+    double* dinv = nullptr;   // [n_cap] 1 / L_ii (every triangular solve multiplies by it)
     double* work = nullptr;   // [2 * n_cap] solve scratch
     double* red = nullptr;    // [4] reductions (logdet, r.alpha)
     int* info = nullptr;      // [1] Cholesky info (0 ok, else 1-based pivot)

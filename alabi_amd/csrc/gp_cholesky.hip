@@ -6,11 +6,14 @@
 // matrix cores (v_mfma_f64_16x16x4_f64) with both 64x64 panels staged in LDS.
 //
 // Per 64-column block step kb:
-//   1. potrf_diag   : one workgroup factorises A[kb,kb] in LDS (reports a non-positive
-//                     pivot as LAPACK's potrf `info`, 1-based).
-//   2. trsm_panel   : A[i,kb] <- A[i,kb] * L_kk^-T for every block row i > kb.  One
-//                     wavefront owns 16 rows; the 4 lanes of a row exchange the solved
-//                     entry with a wave shuffle, so the sweep needs no barrier.
+//   1. potrf_diag   : ONE wavefront factorises A[kb,kb] left-looking: lane i keeps row i in
+//                     registers, finished rows are published to LDS and re-read as broadcasts,
+//                     so a column costs j independent FMAs + one sqrt/reciprocal and there is no
+//                     workgroup barrier.  A non-positive pivot is reported as LAPACK's potrf
+//                     `info` (1-based).  1/L_jj is kept (dinv) for every later triangular solve.
+//   2. trsm_panel   : A[i,kb] <- A[i,kb] * L_kk^-T.  One lane owns one row (64 rows per wave):
+//                     the substitution along the row needs no cross-lane traffic, L_kk is read
+//                     from LDS as broadcasts, divisions are multiplications by dinv.
 //   3. syrk_update  : A[i,j] -= A[i,kb] * A[j,kb]^T for kb < j <= i, one 64x64 tile per
 //                     workgroup, 4 waves x (16 rows x 64 cols) x K=64 on MFMA.
 // The matrix is [Npad, Npad] row-major with identity padding, so every block is full.
@@ -20,75 +23,79 @@ namespace alabi {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(256)
-potrf_diag_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info) {
-    __shared__ double a[64][65];
-    const int tid = threadIdx.x;
+__global__ void __launch_bounds__(64)
+potrf_diag_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info, double* __restrict__ dinv) {
+    __shared__ double Ls[64][65];
+    const int lane = threadIdx.x;
     double* Ab = A + (size_t)(kb * 64) * ld + kb * 64;
-    for (int e = tid; e < 4096; e += 256) {
-        int r = e >> 6, c = e & 63;
-        a[r][c] = (c <= r) ? Ab[(size_t)r * ld + c] : 0.0;
-    }
+    for (int r = 0; r < 64; ++r) Ls[r][lane] = Ab[(size_t)r * ld + lane];   // coalesced rows
     __syncthreads();
-    const int tx = tid & 63, ty = tid >> 6;
+    double a[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) a[k] = Ls[lane][k];   // lane i <- row i (stride 65: conflict-free)
+    __syncthreads();
+    double my_rinv = 1.0;
+#pragma unroll
     for (int j = 0; j < 64; ++j) {
-        double djj = a[j][j];
-        if (!(djj > 0.0)) {  // also true for NaN
-            if (tid == 0) atomicCAS(info, 0, kb * 64 + j + 1);
-            djj = 1.0;
+        // v_i = A_ij - sum_{k<j} L_ik L_jk ; L_jk is row j, published in LDS at earlier columns
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+            const double ljk = Ls[j][k];
+            if ((k & 3) == 0) s0 = fma(a[k], ljk, s0);
+            else if ((k & 3) == 1) s1 = fma(a[k], ljk, s1);
+            else if ((k & 3) == 2) s2 = fma(a[k], ljk, s2);
+            else s3 = fma(a[k], ljk, s3);
         }
-        double ljj = sqrt(djj);
-        __syncthreads();
-        if (tid == j) a[j][j] = ljj;
-        if (tid > j && tid < 64) a[tid][j] = a[tid][j] / ljj;
-        __syncthreads();
-        // trailing update inside the block: a[i][k] -= a[i][j] * a[k][j], j < k <= i
-        if (tx > j) {
-            double akj = a[tx][j];
-            for (int i = j + 1 + ty; i < 64; i += 4) {
-                if (tx <= i) a[i][tx] = fma(-a[i][j], akj, a[i][tx]);
-            }
+        const double v = a[j] - ((s0 + s1) + (s2 + s3));
+        // pivot = v of lane j
+        double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j),
+                                      __builtin_amdgcn_readlane(__double2loint(v), j));
+        if (!(piv > 0.0)) {  // also true for NaN
+            if (lane == 0) atomicCAS(info, 0, kb * 64 + j + 1);
+            piv = 1.0;
         }
-        __syncthreads();
+        const double ljj = sqrt(piv);
+        const double rinv = 1.0 / ljj;
+        a[j] = (lane == j) ? ljj : v * rinv;
+        if (lane == j) my_rinv = rinv;
+        Ls[lane][j] = a[j];          // rows >= j are final in column j (rows < j write unused upper entries)
+        __syncthreads();             // single wave: orders the LDS write before the next column's reads
     }
-    for (int e = tid; e < 4096; e += 256) {
-        int r = e >> 6, c = e & 63;
-        if (c <= r) Ab[(size_t)r * ld + c] = a[r][c];
-    }
+    dinv[kb * 64 + lane] = my_rinv;
+    for (int r = 0; r < 64; ++r)
+        if (lane <= r) Ab[(size_t)r * ld + lane] = Ls[r][lane];
 }
 
-// X * L_kk^T = B for a strip of 16 rows; lane = 4*row + g owns columns c == g (mod 4).
+// X * L_kk^T = B for 64 rows: lane = row, serial along the row, no cross-lane traffic.
 __global__ void __launch_bounds__(64)
-trsm_panel_kernel(double* __restrict__ A, int ld, int kb) {
+trsm_panel_kernel(double* __restrict__ A, int ld, int kb, const double* __restrict__ dinv) {
     __shared__ double lkk[64][65];
+    __shared__ double bs[64][65];
+    __shared__ double di[64];
     const int lane = threadIdx.x;
     const double* Lb = A + (size_t)(kb * 64) * ld + kb * 64;
-    for (int e = lane; e < 4096; e += 64) {
-        int r = e >> 6, c = e & 63;
-        lkk[r][c] = (c <= r) ? Lb[(size_t)r * ld + c] : 0.0;
+    double* Bb = A + (size_t)((kb + 1 + blockIdx.x) * 64) * ld + kb * 64;
+    for (int r = 0; r < 64; ++r) {
+        lkk[r][lane] = Lb[(size_t)r * ld + lane];
+        bs[r][lane] = Bb[(size_t)r * ld + lane];
     }
+    di[lane] = dinv[kb * 64 + lane];
     __syncthreads();
-    const int rl = lane >> 2, g = lane & 3;
-    double* row = A + (size_t)((kb + 1) * 64 + blockIdx.x * 16 + rl) * ld + kb * 64;
-    double b[16];
+    double b[64];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) b[t] = row[4 * t + g];
+    for (int c = 0; c < 64; ++c) b[c] = bs[lane][c];
 #pragma unroll
     for (int c = 0; c < 64; ++c) {
-        const int owner = c & 3, t = c >> 2;
-        double x = b[t] / lkk[c][c];
-        x = __shfl(x, (lane & ~3) | owner, 64);
-        if (g == owner) b[t] = x;
+        const double x = b[c] * di[c];
+        b[c] = x;
 #pragma unroll
-        for (int t2 = 0; t2 < 16; ++t2) {
-            if (4 * t2 + 3 > c) {  // compile-time prune; exact test below
-                int c2 = 4 * t2 + g;
-                if (c2 > c) b[t2] = fma(-x, lkk[c2][c], b[t2]);
-            }
-        }
+        for (int c2 = c + 1; c2 < 64; ++c2) b[c2] = fma(-x, lkk[c2][c], b[c2]);
     }
 #pragma unroll
-    for (int t = 0; t < 16; ++t) row[4 * t + g] = b[t];
+    for (int c = 0; c < 64; ++c) bs[lane][c] = b[c];
+    __syncthreads();
+    for (int r = 0; r < 64; ++r) Bb[(size_t)r * ld + lane] = bs[r][lane];
 }
 
 // C[bi,bj] -= P[bi] * P[bj]^T with P[b] = A[b-block rows, kb-block cols].
@@ -110,7 +117,6 @@ syrk_update_kernel(double* __restrict__ A, int ld, int kb) {
         Pi[r][c] = Ai[(size_t)r * ld + c];
         Pj[r][c] = Aj[(size_t)r * ld + c];
     }
-    __syncthreads();
     const int w = tid >> 6, l = tid & 63;
     const int lr = l & 15, lk = l >> 4;
     double* C = A + (size_t)(bi * 64 + 16 * w) * ld + bj * 64;
@@ -119,6 +125,7 @@ syrk_update_kernel(double* __restrict__ A, int ld, int kb) {
     for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[n][i] = C[(size_t)(lk + 4 * i) * ld + 16 * n + lr];
+    __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
         double a = -Pi[16 * w + lr][4 * ks + lk];
@@ -138,10 +145,10 @@ int launch_cholesky(alabi_gp* gp, hipStream_t s) {
     const int ld = gp->Npad, nb = gp->Npad / 64;
     ALABI_HIP_CHECK(hipMemsetAsync(gp->info, 0, sizeof(int), s));
     for (int kb = 0; kb < nb; ++kb) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, s, gp->L, ld, kb, gp->info);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, s, gp->L, ld, kb, gp->info, gp->dinv);
         int T = nb - kb - 1;
         if (T > 0) {
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3(T * 4), dim3(64), 0, s, gp->L, ld, kb);
+            hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(64), 0, s, gp->L, ld, kb, gp->dinv);
             hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, s, gp->L, ld, kb);
         }
     }

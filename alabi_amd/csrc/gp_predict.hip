@@ -78,15 +78,16 @@ predict_mean_tile_kernel(const double* __restrict__ Xt, const double* __restrict
 }
 
 template <int D>
-__global__ void __launch_bounds__(256)
-predict_var_kernel(const double* __restrict__ L, const double* __restrict__ Xt, const double* __restrict__ alpha,
-                   int N, int Npad, const double* __restrict__ Xs, int d, long long M, DimVec inv_len,
+__global__ void __launch_bounds__(256, 2)
+predict_var_kernel(const double* __restrict__ L, const double* __restrict__ dinv, const double* __restrict__ Xt,
+                   const double* __restrict__ alpha, int N, int Npad, const double* __restrict__ Xs, int d, long long M, DimVec inv_len,
                    double amp, double mean, double* __restrict__ ws, double* __restrict__ mu,
                    double* __restrict__ var) {
     __shared__ double As[64][66];   // L[kb,j] block, then L[kb,kb]
     __shared__ double Vs[64][80];   // V_j tile (MFMA B operand), then the C tile
     __shared__ double xtr[D][64];   // scaled coordinates of training block kb
     __shared__ double alb[64];
+    __shared__ double dis[64];      // 1 / L_rr of block kb
     const int tid = threadIdx.x, c = tid & 63, w = tid >> 6;
     const int lr = c & 15, lk = c >> 4;  // MFMA lane decomposition within the wave
     const int nb = Npad / 64, ld = Npad;
@@ -101,7 +102,7 @@ predict_var_kernel(const double* __restrict__ L, const double* __restrict__ Xt, 
         for (int kb = 0; kb < nb; ++kb) {
             __syncthreads();
             for (int e = tid; e < D * 64; e += 256) xtr[e >> 6][e & 63] = Xt[(size_t)(e >> 6) * Npad + kb * 64 + (e & 63)];
-            if (tid < 64) alb[tid] = alpha[kb * 64 + tid];
+            if (tid < 64) { alb[tid] = alpha[kb * 64 + tid]; dis[tid] = dinv[kb * 64 + tid]; }
             __syncthreads();
             // K* block: thread (column c, wave w) evaluates rows 16w .. 16w+15
 #pragma unroll 4
@@ -164,7 +165,7 @@ predict_var_kernel(const double* __restrict__ L, const double* __restrict__ Xt, 
 #pragma unroll
             for (int r = 0; r < 64; ++r) {
                 const int owner = r & 3, t = r >> 2;
-                double x = v[t] / As[r][r];
+                double x = v[t] * dis[r];
                 x = __shfl(x, lr + 16 * owner, 64);
                 if (lk == owner) v[t] = x;
 #pragma unroll
@@ -229,7 +230,7 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
         gp->ws_bytes = need;
     }
     const double amp = exp(gp->log_amp);
-    ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(predict_var_kernel<D>, dim3(grid), dim3(256), 0, s, gp->L, gp->Xt,
+    ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(predict_var_kernel<D>, dim3(grid), dim3(256), 0, s, gp->L, gp->dinv, gp->Xt,
                                               gp->alpha, gp->N, gp->Npad, Xs, gp->d, M, gp->inv_len, amp,
                                               gp->mean, gp->ws, mu, var));
     ALABI_LAUNCH_CHECK();

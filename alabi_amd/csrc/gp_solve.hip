@@ -9,18 +9,17 @@
 // diagonal system in one wavefront (lane i holds row i, the solved entry is broadcast with
 // a wave shuffle) and then applies its own 64x64 block of the update, so a step is ONE
 // kernel and the steps are ordered by the stream.  2 N^2 flops, latency bound: once per refit.
-#include "common.hpp"
+#include "gp_device.hpp"
 
 namespace alabi {
 
 // Forward step kb: z_kb = L_kk^-1 r_kb ; r_i -= L[i,kb] z_kb for i > kb.
 // blockIdx.x = i - kb.  r is updated in place below block kb; z is written to `z`.
 __global__ void __launch_bounds__(256)
-trsv_fwd_step_kernel(const double* __restrict__ L, int ld, int kb, double* __restrict__ r,
-                     double* __restrict__ z) {
+trsv_fwd_step_kernel(const double* __restrict__ L, int ld, int kb, const double* __restrict__ dinv,
+                     double* __restrict__ r, double* __restrict__ z) {
     __shared__ double lkk[64][65];
     __shared__ double zs[64];
-    __shared__ double part[4][64];
     const int tid = threadIdx.x;
     const double* Lb = L + (size_t)(kb * 64) * ld + kb * 64;
     for (int e = tid; e < 4096; e += 256) {
@@ -30,8 +29,10 @@ trsv_fwd_step_kernel(const double* __restrict__ L, int ld, int kb, double* __res
     __syncthreads();
     if (tid < 64) {
         double v = r[kb * 64 + tid];
+        const double di = dinv[kb * 64 + tid];
+#pragma unroll
         for (int j = 0; j < 64; ++j) {
-            double zj = __shfl(v / lkk[j][j], j, 64);
+            const double zj = lane_bcast(v * di, j);   // v_readlane with a static lane: no LDS round trip
             if (tid == j) v = zj;
             if (tid > j) v = fma(-lkk[tid][j], zj, v);
         }
@@ -50,14 +51,13 @@ trsv_fwd_step_kernel(const double* __restrict__ L, int ld, int kb, double* __res
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     if (q == 0) r[i * 64 + row] -= s;
-    (void)part;
 }
 
 // Backward step kb: a_kb = L_kk^-T z_kb ; z_i -= L[kb,i]^T a_kb for i < kb.  blockIdx.x = i
 // for i < kb, and blockIdx.x == kb is the block that publishes a_kb.
 __global__ void __launch_bounds__(256)
-trsv_bwd_step_kernel(const double* __restrict__ L, int ld, int kb, double* __restrict__ z,
-                     double* __restrict__ alpha) {
+trsv_bwd_step_kernel(const double* __restrict__ L, int ld, int kb, const double* __restrict__ dinv,
+                     double* __restrict__ z, double* __restrict__ alpha) {
     __shared__ double lkk[64][65];
     __shared__ double as[64];
     __shared__ double part[4][64];
@@ -70,8 +70,10 @@ trsv_bwd_step_kernel(const double* __restrict__ L, int ld, int kb, double* __res
     __syncthreads();
     if (tid < 64) {
         double v = z[kb * 64 + tid];
+        const double di = dinv[kb * 64 + tid];
+#pragma unroll
         for (int j = 63; j >= 0; --j) {
-            double aj = __shfl(v / lkk[j][j], j, 64);
+            const double aj = lane_bcast(v * di, j);
             if (tid == j) v = aj;
             if (tid < j) v = fma(-lkk[j][tid], aj, v);  // (L^T)[tid][j] = L[j][tid]
         }
@@ -126,9 +128,9 @@ int launch_alpha(alabi_gp* gp, hipStream_t s) {
     hipLaunchKernelGGL(residual_kernel, dim3((gp->Npad + 255) / 256), dim3(256), 0, s, gp->y, gp->N,
                        gp->Npad, gp->mean, r);
     for (int kb = 0; kb < nb; ++kb)
-        hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(nb - kb), dim3(256), 0, s, gp->L, ld, kb, r, z);
+        hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(nb - kb), dim3(256), 0, s, gp->L, ld, kb, gp->dinv, r, z);
     for (int kb = nb - 1; kb >= 0; --kb)
-        hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(kb + 1), dim3(256), 0, s, gp->L, ld, kb, z, gp->alpha);
+        hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(kb + 1), dim3(256), 0, s, gp->L, ld, kb, gp->dinv, z, gp->alpha);
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }
