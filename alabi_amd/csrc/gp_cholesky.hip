@@ -55,8 +55,14 @@ potrf_diag_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info
             if (lane == 0) atomicCAS(info, 0, kb * 64 + j + 1);
             piv = 1.0;
         }
-        const double ljj = sqrt(piv);
-        const double rinv = 1.0 / ljj;
+        // 1/sqrt(piv) from the hardware estimate + two Newton steps (full fp64), then L_jj = piv * rinv with
+        // one correction step: ~12 dependent ops instead of an IEEE sqrt followed by an IEEE division.
+        double rinv = __builtin_amdgcn_rsq(piv);
+        rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+        rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+        double ljj = piv * rinv;
+        ljj = fma(0.5 * rinv, fma(-ljj, ljj, piv), ljj);
+        rinv = fma(rinv, fma(-ljj, rinv, 1.0), rinv);   // rinv = 1 / L_jj to working precision
         a[j] = (lane == j) ? ljj : v * rinv;
         if (lane == j) my_rinv = rinv;
         Ls[lane][j] = a[j];          // rows >= j are final in column j (rows < j write unused upper entries)
