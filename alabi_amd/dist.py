@@ -85,7 +85,13 @@ class ShardedEnsemble:
         send[: e - b, : self.d] = coords.index_select(0, mine)
         send[: e - b, self.d] = logp.index_select(0, mine)
         recv = torch.empty((self.world * per, self.d + 1), dtype=torch.float64, device=coords.device)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":
+            # test rig only (several ranks sharing ONE GPU cannot use RCCL): stage the same all-gather through host memory
+            recv_h = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(recv_h, send.cpu(), group=self.group)
+            recv.copy_(recv_h)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
         for r in range(self.world):
             rb, re = slice_bounds(nS, self.world, r)
             if r == self.rank or re == rb:
@@ -117,8 +123,13 @@ class ShardedEnsemble:
                 if nstore and k % thin_by == 0:
                     chain[k // thin_by - 1] = coords
             done += n
-        if self.world > 1:
-            dist.all_reduce(n_accept, group=self.group)   # each walker was counted by exactly one rank
+        if self.world > 1:   # each walker was counted by exactly one rank
+            if n_accept.is_cuda and dist.get_backend(self.group) == "gloo":
+                h = n_accept.cpu()
+                dist.all_reduce(h, group=self.group)
+                n_accept.copy_(h)
+            else:
+                dist.all_reduce(n_accept, group=self.group)
         return chain, coords, logp, n_accept
 
 

@@ -174,8 +174,20 @@ def main():
         flops_per_launch = n_prop * N * (2 * d + 3)
         us_per_launch = 1e3 * ev_ms / (args.steps * launches_per_step)
         achieved = flops_per_launch / (us_per_launch * 1e-6) / 1e12
+        # HBM/fabric bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE, then
+        # --pmc WRITE_SIZE, same command; FETCH_SIZE doubled for 16-B-per-lane streaming reads per
+        # MI355X_MICROARCH.md section HBM).  A PMC pass cannot run inside this process, so the number is read from
+        # profiles/ and is null when the file is absent or the workload differs from the profiled one.
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_by_kernel.json")
+        if os.path.exists(pmc_path) and args.config == "C3" and args.ensembles == 1 and not shard:
+            try:
+                pmc = json.load(open(pmc_path))["void alabi::ens_half_kernel<10>"]
+                traffic = (2.0 * pmc["FETCH_SIZE"]["mean_KB"] + pmc["WRITE_SIZE"]["mean_KB"]) * 1024.0
+            except Exception:  # noqa: BLE001
+                traffic = None
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                           "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                            "kernel": "ens_half_kernel<10>", "us_per_launch_incl_boundary": us_per_launch,
                            "flops_per_launch": flops_per_launch,
                            "note": "fp64 vector peak == fp64 matrix peak on MI355X; latency-bound kernel, see DESIGN.md"}
