@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libalabi_hip.so")
 
-OK, NOT_PD, BAD_ARG, HIP_ERROR, NOT_COMPUTED = 0, 1, 2, 3, 4
+OK, NOT_PD, BAD_ARG, HIP_ERROR, NOT_COMPUTED, TIMEOUT = 0, 1, 2, 3, 4, 5
 UTILITY_CODES = {"bape": 0, "agp": 1, "jones": 2}
 MAX_DIM = 64
 
@@ -47,6 +47,7 @@ SIGNATURES = {
     "alabi_utility_eval": (_i, [_i, _vp, _ll, _i, _pd, _d, _vp, _vp, _vp, _vp]),
     "alabi_ens_create": (_i, [_vp, _i, _i, _i, _pd, _ull, C.POINTER(_vp)]),
     "alabi_ens_destroy": (_i, [_vp]),
+    "alabi_ens_set_stream": (_i, [_vp, _i]),
     "alabi_ens_lnprob": (_i, [_vp, _vp, _vp, _vp]),
     "alabi_ens_run": (_i, [_vp, _vp, _vp, _ll, _ll, _i, _d, _vp, _vp, _vp, _vp]),
     "alabi_ens_draw": (_i, [_vp, _ll, _i, _d, _vp]),

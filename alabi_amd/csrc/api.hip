@@ -37,6 +37,7 @@ const char* alabi_status_string(int status) {
         case ALABI_BAD_ARGUMENT: return "bad argument";
         case ALABI_HIP_ERROR: return "HIP runtime error";
         case ALABI_NOT_COMPUTED: return "GP not computed / y not set";
+        case ALABI_TIMEOUT: return "persistent ensemble kernel timed out waiting for a hand-off";
         default: return "unknown status";
     }
 }
@@ -316,6 +317,19 @@ int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* 
     if (err == hipSuccess) err = hipMalloc(&b.u_acc, n * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&e->run_state, 4 * sizeof(long long));
     if (err == hipSuccess) err = hipMalloc(&e->consts, 3 * ALABI_MAX_DIM * sizeof(double));
+    // persistent dataflow path: one workgroup per list position, all co-resident (at most one per CU)
+    {
+        int dev = 0, n_cu = 0;
+        const char* env = getenv("ALABI_ENS_STREAM");
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            (long long)((W + 1) / 2) * n_ensembles <= n_cu && !(env && env[0] == '0')) {
+            const size_t hist_words = ((size_t)e->chunk_cap + 1) * WT * (d + 1);
+            if (err == hipSuccess) err = hipMalloc(&e->hist, hist_words * sizeof(unsigned long long));
+            if (err == hipSuccess) err = hipMalloc(&e->err, sizeof(int));
+            e->stream_ok = (err == hipSuccess) ? 1 : 0;
+        }
+    }
     if (err != hipSuccess) {
         alabi_ens_destroy(e);
         return hip_fail(err, "hipMalloc(ensemble buffers)", __FILE__, __LINE__);
@@ -330,7 +344,16 @@ int alabi_ens_destroy(alabi_ens* e) {
     free_draws(e->draws);
     if (e->run_state) (void)hipFree(e->run_state);
     if (e->consts) (void)hipFree(e->consts);
+    if (e->hist) (void)hipFree(e->hist);
+    if (e->err) (void)hipFree(e->err);
     delete e;
+    return ALABI_OK;
+}
+
+int alabi_ens_set_stream(alabi_ens* e, int enabled) {
+    if (!e) return ALABI_BAD_ARGUMENT;
+    if (enabled && !(e->hist && e->err)) return ALABI_BAD_ARGUMENT;
+    e->stream_ok = enabled ? 1 : 0;
     return ALABI_OK;
 }
 
@@ -401,6 +424,23 @@ int alabi_ens_run(alabi_ens* e, double* coords, double* logp, long long step0, l
     int st;
     if ((st = sync_consts(e, s)) != ALABI_OK) return st;
     if ((st = set_run_state(e, step0, 0, s)) != ALABI_OK) return st;
+    // Persistent dataflow path: training set pinned in registers (needs Npad <= 2 points x 1024 lanes), one
+    // workgroup per list position.  It synchronises at the end to read the time-out flag.
+    if (e->stream_ok && s != nullptr && e->gp->Npad <= 2048 && a == a) {
+        ALABI_HIP_CHECK(hipMemsetAsync(e->err, 0, sizeof(int), s));
+        long long remaining = nsteps;
+        while (remaining > 0) {
+            const int K = (int)(remaining < e->chunk_cap ? remaining : e->chunk_cap);
+            if ((st = launch_ens_draw(e, K, a, s)) != ALABI_OK) return st;
+            if ((st = launch_ens_stream(e, coords, logp, K, thin_by, chain, chain_logp, n_accept, s)) != ALABI_OK) return st;
+            if ((st = launch_ens_advance(e, K, s)) != ALABI_OK) return st;
+            remaining -= K;
+        }
+        int flag = 0;
+        ALABI_HIP_CHECK(hipMemcpyAsync(&flag, e->err, sizeof(int), hipMemcpyDeviceToHost, s));
+        ALABI_HIP_CHECK(hipStreamSynchronize(s));
+        return flag ? ALABI_TIMEOUT : ALABI_OK;
+    }
     HalfArgs h = base_args(e, coords, logp);
     h.chain = chain; h.chain_logp = chain_logp; h.n_accept = n_accept; h.thin_by = thin_by;
 

@@ -103,6 +103,10 @@ struct alabi_ens {
     } graph_key{};
     int graph_steps = 0;
     long long* run_state = nullptr;  // device [4]: [0] first global step of the chunk, [1] steps done before it
+    // persistent dataflow path (ens_stream_kernel)
+    unsigned long long* hist = nullptr;  // [(chunk_cap+1)][E*W][d+1] version history of every walker
+    int* err = nullptr;                  // [1] spin time-out flag
+    int stream_ok = 0;                   // eligible: training set fits the lanes' registers, one workgroup per CU
 };
 
 namespace alabi {
@@ -147,4 +151,6 @@ int launch_ens_prep(alabi_ens* e, const int* order, int n0, const double* u_z, c
 int launch_ens_half_args(alabi_ens* e, const HalfArgs& args, int nblocks, hipStream_t s);
 int launch_ens_lnprob(alabi_ens* e, const double* coords, int nwalkers, double* logp, hipStream_t s);
 int launch_ens_advance(alabi_ens* e, long long n, hipStream_t s);
+int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
+                      long long* n_accept, hipStream_t s);
 }  // namespace alabi

@@ -281,6 +281,211 @@ __global__ void ens_advance_kernel(long long* run_state, long long n) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { run_state[0] += n; run_state[1] += n; }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Persistent dataflow variant ("stream" kernel).  One workgroup per list position b (and ensemble) lives for
+// K whole steps.  Its share of the training set (2 points x (D + 1) doubles per lane) is loaded ONCE and stays
+// in VGPRs, so a proposal costs the distance/exp/reduction only.  There is no barrier between half steps: the
+// state of every walker after every step is a row of the version history `hist[v][walker] = (coords, logp)`
+// (v = number of steps that walker has completed; immutable once written), and a proposal waits only for the
+// two rows it reads -- its own walker at version t and its partner at version t (+1 if the partner belongs to
+// the half already updated in this step).  Hand-off follows cdna_hip_programming.md Guideline 16 form R2 (the
+// data is the flag): rows of versions 1..K start as a sentinel NaN; every word is written by ONE aligned 8-byte
+// write-through store (sc1 = relaxed agent-scope atomic store) and the consumer's lanes poll their own words
+// with sc1 loads (L1 bypassed) until none is the sentinel -- no release fence, no drain, no separate flag word.
+// Correctness never depends on placement or timing; every spin is bounded
+// (a timeout sets *err and every workgroup leaves, the host then falls back to the launch-per-half-step path).
+// All workgroups must be co-resident: the host launches at most one per CU.
+#define ALABI_HIST_EMPTY 0x7FF8A1AB1D15EA5Eull   // quiet NaN with a payload no computation produces
+
+struct StreamArgs {
+    unsigned long long* hist;    // [(K+1)][E*W][d+1] as raw 64-bit words; rows 1..K pre-filled with ALABI_HIST_EMPTY
+    int* err;                    // [1], zeroed before the launch
+    DrawBuffers rec;             // chunk base
+    const double* consts;
+    const double* Xt;
+    const double* alpha;
+    double* chain;
+    double* chain_logp;
+    unsigned long long* n_accept;
+    const long long* run_state;
+    int K, W, n0, d, Npad, thin_by, spin_limit;
+    double amp, mean;
+};
+
+__device__ inline unsigned long long ld_sc1(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void st_sc1(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int D>
+__global__ void __launch_bounds__(1024)
+ens_stream_kernel(StreamArgs p) {
+    __shared__ double qs_s[ALABI_MAX_DIM];
+    __shared__ double scratch[16];
+    __shared__ int ctl_s[2];   // [0] proposal in bounds, [1] abort
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int b = blockIdx.x, e = blockIdx.y, E = gridDim.y;
+    const int WT = p.W * E, row = p.d + 1;
+    // training-set share of this lane, resident for the whole launch
+    const int half = p.Npad >> 1;
+    const bool vA = tid < half;
+    f64x2 xa[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        xa[k] = vA ? reinterpret_cast<const f64x2*>(p.Xt + (size_t)k * p.Npad)[tid] : f64x2{0.0, 0.0};
+    const f64x2 aa = vA ? reinterpret_cast<const f64x2*>(p.alpha)[tid] : f64x2{0.0, 0.0};
+    const double* inv_len = p.consts;
+    const double* lo = p.consts + ALABI_MAX_DIM;
+    const double* hi = p.consts + 2 * ALABI_MAX_DIM;
+    if (tid == 0) ctl_s[1] = 0;
+    __syncthreads();
+
+    // proposal records are read one proposal ahead (they depend on nothing), so their latency is off the chain
+    int n_w = 0, n_cw = 0;
+    double n_zz = 0.0, n_lnfac = 0.0, n_lnu = 0.0;
+    auto fetch_record = [&](int t, int split) {
+        if (tid < 64 && t < p.K && b < (split ? p.W - p.n0 : p.n0)) {
+            const size_t pos = ((size_t)t * E + e) * p.W + (split ? p.n0 : 0) + b;
+            n_w = p.rec.order[pos]; n_cw = p.rec.cw[pos];
+            n_zz = p.rec.zz[pos]; n_lnfac = p.rec.lnfac[pos]; n_lnu = p.rec.lnu[pos];
+        }
+    };
+    fetch_record(0, 0);
+    for (int t = 0; t < p.K; ++t) {
+        for (int split = 0; split < 2; ++split) {
+            const int nS = split ? p.W - p.n0 : p.n0;
+            if (b >= nS) { fetch_record(split ? t + 1 : t, split ? 0 : 1); continue; }   // workgroup-uniform
+            int w = 0;
+            double qv = 0.0, sv = 0.0, lnfac = 0.0, lnu = 0.0;   // lane k < d: coordinate k; lane d: logp
+            if (tid < 64) {                                           // wave 0 fetches the two rows it depends on
+                w = n_w;
+                const int cw = n_cw;
+                const double zz = n_zz;
+                lnfac = n_lnfac; lnu = n_lnu;
+                fetch_record(split ? t + 1 : t, split ? 0 : 1);
+                // own row at version t, partner row at version t (+1 when the partner's half went first)
+                const unsigned long long* hw = p.hist + ((size_t)t * WT + w) * row;
+                const unsigned long long* hc = p.hist + ((size_t)(t + split) * WT + cw) * row;
+                // The data IS the flag (Guideline 16 form R2): every word of a row is one aligned 8-byte sc1 store
+                // over a sentinel NaN that no coordinate or log-probability can equal; lane k polls its own words.
+                unsigned long long ws = ALABI_HIST_EMPTY, wc = ALABI_HIST_EMPTY;
+                int ok = 1, spins = 0;
+                const bool mine = tid <= p.d, needc = tid < p.d;
+                while (true) {
+                    if (mine && ws == ALABI_HIST_EMPTY) ws = ld_sc1(hw + tid);
+                    if (needc && wc == ALABI_HIST_EMPTY) wc = ld_sc1(hc + tid);
+                    const int ready = (!mine || ws != ALABI_HIST_EMPTY) && (!needc || wc != ALABI_HIST_EMPTY);
+                    if (__all(ready)) break;
+                    if (++spins > p.spin_limit ||
+                        ((spins & 63) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        ok = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ok && tid == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int inb = 1;
+                if (ok && mine) {
+                    sv = __longlong_as_double((long long)ws);
+                    if (needc) {
+                        const double cv = __longlong_as_double((long long)wc);
+                        qv = cv - (cv - sv) * zz;
+                        inb = (qv > lo[tid]) && (qv < hi[tid]);
+                        qs_s[tid] = qv * inv_len[tid];
+                    }
+                }
+                if (tid >= p.d && tid < D) qs_s[tid] = 0.0;
+                const int all_in = __all(inb);
+                if (tid == 0) { ctl_s[0] = all_in; if (!ok) ctl_s[1] = 1; }
+            }
+            __syncthreads();
+            if (ctl_s[1]) return;                                     // timed out somewhere: leave (host falls back)
+            const int inb = ctl_s[0];
+            double lp_new = -INFINITY;
+            if (inb) {
+                double q[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) q[k] = qs_s[k];
+                double r2a = 0.0, r2b = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const double da = xa[k].x - q[k], db = xa[k].y - q[k];
+                    r2a = fma(da, da, r2a);
+                    r2b = fma(db, db, r2b);
+                }
+                double acc = aa.x * exp(-0.5 * r2a);
+                acc = fma(aa.y, exp(-0.5 * r2b), acc);
+                const double wsum = wave_sum_dpp(acc);
+                if ((tid & 63) == 63) scratch[tid >> 6] = wsum;
+            }
+            __syncthreads();                                          // also frees qs_s / ctl_s for the next proposal
+            if (tid < 64) {
+                if (inb) {
+                    const int nw = T >> 6;
+                    double part = (tid < nw) ? scratch[tid] : 0.0;
+                    part = wave_sum_dpp(part);
+                    lp_new = fma(p.amp, lane_bcast(part, 63), p.mean);
+                }
+                const double lp_old = lane_bcast(sv, p.d);            // lane d loaded logp
+                const int acc_flag = (lnfac + lp_new - lp_old > lnu) ? 1 : 0;
+                // new row of the walker: lanes k < d coordinates, lane d logp
+                double outv = (tid < p.d) ? (acc_flag ? qv : sv) : (acc_flag ? lp_new : lp_old);
+                if (tid <= p.d) {
+                    st_sc1(p.hist + ((size_t)(t + 1) * WT + w) * row + tid, (unsigned long long)__double_as_longlong(outv));
+                    const long long done = p.run_state[1] + t + 1;
+                    if (done % p.thin_by == 0) {
+                        const size_t slot = (size_t)(done / p.thin_by - 1);
+                        if (tid < p.d) { if (p.chain) __builtin_nontemporal_store(outv, &p.chain[(slot * WT + w) * p.d + tid]); }
+                        else if (p.chain_logp) __builtin_nontemporal_store(outv, &p.chain_logp[slot * WT + w]);
+                    }
+                }
+                if (tid == 0 && acc_flag && p.n_accept) atomicAdd(p.n_accept + w, 1ull);
+            }
+        }
+    }
+}
+
+// hist[0] <- (coords, logp); and back: (coords, logp) <- hist[K]
+__global__ void __launch_bounds__(256)
+ens_hist_fill_kernel(unsigned long long* __restrict__ h, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) h[i] = ALABI_HIST_EMPTY;
+}
+
+__global__ void __launch_bounds__(256)
+ens_hist_copy_kernel(double* __restrict__ coords, double* __restrict__ logp, unsigned long long* __restrict__ hist_row,
+                     int WT, int d, int to_hist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= WT * (d + 1)) return;
+    const int w = i / (d + 1), k = i % (d + 1);
+    double* src = (k < d) ? coords + (size_t)w * d + k : logp + w;
+    if (to_hist) hist_row[i] = (unsigned long long)__double_as_longlong(*src);
+    else *src = __longlong_as_double((long long)hist_row[i]);
+}
+
+int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
+                      long long* n_accept, hipStream_t s) {
+    alabi_gp* gp = e->gp;
+    const int WT = e->W * e->E, row = e->d + 1;
+    const int n0 = (e->W + 1) / 2;
+    hipLaunchKernelGGL(ens_hist_fill_kernel, dim3(1024), dim3(256), 0, s, e->hist + (size_t)WT * row, (size_t)K * WT * row);
+    hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp, e->hist, WT, e->d, 1);
+    StreamArgs a{};
+    a.hist = e->hist; a.err = e->err; a.rec = e->draws; a.consts = e->consts;
+    a.Xt = gp->Xt; a.alpha = gp->alpha; a.chain = chain; a.chain_logp = chain_logp;
+    a.n_accept = reinterpret_cast<unsigned long long*>(n_accept); a.run_state = e->run_state;
+    a.K = K; a.W = e->W; a.n0 = n0; a.d = e->d; a.Npad = gp->Npad; a.thin_by = thin_by; a.spin_limit = 1 << 20;
+    a.amp = exp(gp->log_amp); a.mean = gp->mean;
+    const int db = dim_bucket(e->d);
+    ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(ens_stream_kernel<D>, dim3(n0, e->E), dim3(1024), 0, s, a));
+    hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp,
+                       e->hist + (size_t)K * WT * row, WT, e->d, 0);
+    ALABI_LAUNCH_CHECK();
+    return ALABI_OK;
+}
+
 int launch_ens_draw(alabi_ens* e, int nsteps, double a, hipStream_t s) {
     const size_t lds = (size_t)e->W * 16;
     hipLaunchKernelGGL(ens_draw_kernel, dim3(nsteps, e->E), dim3(256), lds, s, e->seed, e->run_state, e->W, e->d, a,

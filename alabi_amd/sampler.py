@@ -162,10 +162,23 @@ class EnsembleSampler:
         chain_lp = torch.empty((nstore, self.total_walkers), dtype=torch.float64, device=dev) if nstore else None
         t0 = time.perf_counter()
         self._stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._stream):
-            st = _lib.lib().alabi_ens_run(self._ens, _lib.ptr(self._coords), _lib.ptr(self._logp), self.iteration, nsteps,
-                                          thin_by, self.a, _lib.ptr(chain), _lib.ptr(chain_lp), _lib.ptr(self._naccept),
-                                          C.c_void_p(self._stream.cuda_stream))
+        backup = (self._coords.clone(), self._logp.clone(), self._naccept.clone())
+
+        def _run():
+            with torch.cuda.stream(self._stream):
+                return _lib.lib().alabi_ens_run(self._ens, _lib.ptr(self._coords), _lib.ptr(self._logp), self.iteration,
+                                                nsteps, thin_by, self.a, _lib.ptr(chain), _lib.ptr(chain_lp),
+                                                _lib.ptr(self._naccept), C.c_void_p(self._stream.cuda_stream))
+
+        st = _run()
+        if st == _lib.TIMEOUT:
+            # the persistent kernel gave up on a hand-off (e.g. the GPU was shared and its workgroups were not all
+            # resident): restore the state and repeat the run with one launch per half step
+            self._stream.synchronize()
+            self._coords.copy_(backup[0]); self._logp.copy_(backup[1]); self._naccept.copy_(backup[2])
+            _lib.check(_lib.lib().alabi_ens_set_stream(self._ens, 0), "alabi_ens_set_stream")
+            self.stream_fallbacks = getattr(self, "stream_fallbacks", 0) + 1
+            st = _run()
         _lib.check(st, "alabi_ens_run")
         self._stream.synchronize()
         torch.cuda.current_stream().wait_stream(self._stream)

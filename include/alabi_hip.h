@@ -28,6 +28,8 @@ extern "C" {
 #define ALABI_BAD_ARGUMENT 2
 #define ALABI_HIP_ERROR 3
 #define ALABI_NOT_COMPUTED 4          /* predict / set_y before a successful compute */
+#define ALABI_TIMEOUT 5               /* persistent ensemble kernel: a bounded spin ran out (state is invalid; re-run
+                                         with ALABI_ENS_STREAM=0) */
 
 #define ALABI_UTILITY_BAPE 0
 #define ALABI_UTILITY_AGP 1
@@ -109,6 +111,9 @@ int alabi_utility_eval(int algo, const double* Xs, long long M, int d, const dou
 int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* bounds,
                      unsigned long long seed, alabi_ens** out);
 int alabi_ens_destroy(alabi_ens* ens);
+/* Enable / disable the persistent dataflow kernel for alabi_ens_run on this handle (default: enabled when the
+ * ensemble fits one workgroup per CU).  Returns ALABI_BAD_ARGUMENT when enabling is impossible. */
+int alabi_ens_set_stream(alabi_ens* ens, int enabled);
 
 /* log-probability of every walker (surrogate mean + box prior): coords [E*W,d] -> logp [E*W]. */
 int alabi_ens_lnprob(alabi_ens* ens, const double* coords, double* logp, void* stream);
