@@ -357,6 +357,12 @@ int alabi_ens_set_stream(alabi_ens* e, int enabled) {
     return ALABI_OK;
 }
 
+int alabi_ens_last_path(alabi_ens* e, int* path) {
+    if (!e || !path) return ALABI_BAD_ARGUMENT;
+    *path = e->last_path;
+    return ALABI_OK;
+}
+
 // (inv_len, lo, hi) live in device memory; refreshed whenever the GP's hyper-parameters changed.
 static int sync_consts(alabi_ens* e, hipStream_t s) {
     if (e->consts_gen == e->gp->gen) return ALABI_OK;
@@ -426,7 +432,9 @@ int alabi_ens_run(alabi_ens* e, double* coords, double* logp, long long step0, l
     if ((st = set_run_state(e, step0, 0, s)) != ALABI_OK) return st;
     // Persistent dataflow path: training set pinned in registers (needs Npad <= 2 points x 1024 lanes), one
     // workgroup per list position.  It synchronises at the end to read the time-out flag.
-    if (e->stream_ok && s != nullptr && e->gp->Npad <= 2048 && a == a) {
+    e->last_path = 0;
+    if (e->stream_ok && s != nullptr && ens_stream_fits(e)) {
+        e->last_path = 1;
         ALABI_HIP_CHECK(hipMemsetAsync(e->err, 0, sizeof(int), s));
         long long remaining = nsteps;
         while (remaining > 0) {

@@ -106,6 +106,7 @@ struct alabi_ens {
     // persistent dataflow path (ens_stream_kernel)
     unsigned long long* hist = nullptr;  // [(chunk_cap+1)][E*W][d+1] version history of every walker
     int* err = nullptr;                  // [1] spin time-out flag
+    int last_path = 0;                   // 1 if the last run used the persistent kernel
     int stream_ok = 0;                   // eligible: training set fits the lanes' registers, one workgroup per CU
 };
 
@@ -151,6 +152,7 @@ int launch_ens_prep(alabi_ens* e, const int* order, int n0, const double* u_z, c
 int launch_ens_half_args(alabi_ens* e, const HalfArgs& args, int nblocks, hipStream_t s);
 int launch_ens_lnprob(alabi_ens* e, const double* coords, int nwalkers, double* logp, hipStream_t s);
 int launch_ens_advance(alabi_ens* e, long long n, hipStream_t s);
+bool ens_stream_fits(const alabi_ens* e);
 int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
                       long long* n_accept, hipStream_t s);
 }  // namespace alabi

@@ -320,8 +320,8 @@ __device__ inline void st_sc1(unsigned long long* p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int D>
-__global__ void __launch_bounds__(1024)
+template <int D, int PPT, int TMAX>
+__global__ void __launch_bounds__(TMAX)
 ens_stream_kernel(StreamArgs p) {
     __shared__ double qs_s[ALABI_MAX_DIM];
     __shared__ double scratch[16];
@@ -331,12 +331,16 @@ ens_stream_kernel(StreamArgs p) {
     const int WT = p.W * E, row = p.d + 1;
     // training-set share of this lane, resident for the whole launch
     const int half = p.Npad >> 1;
-    const bool vA = tid < half;
-    f64x2 xa[D];
+    f64x2 xa[PPT][D], aa[PPT];
 #pragma unroll
-    for (int k = 0; k < D; ++k)
-        xa[k] = vA ? reinterpret_cast<const f64x2*>(p.Xt + (size_t)k * p.Npad)[tid] : f64x2{0.0, 0.0};
-    const f64x2 aa = vA ? reinterpret_cast<const f64x2*>(p.alpha)[tid] : f64x2{0.0, 0.0};
+    for (int j = 0; j < PPT; ++j) {
+        const int idx = tid + j * T;
+        const bool v = idx < half;
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            xa[j][k] = v ? reinterpret_cast<const f64x2*>(p.Xt + (size_t)k * p.Npad)[idx] : f64x2{0.0, 0.0};
+        aa[j] = v ? reinterpret_cast<const f64x2*>(p.alpha)[idx] : f64x2{0.0, 0.0};
+    }
     const double* inv_len = p.consts;
     const double* lo = p.consts + ALABI_MAX_DIM;
     const double* hi = p.consts + 2 * ALABI_MAX_DIM;
@@ -409,15 +413,20 @@ ens_stream_kernel(StreamArgs p) {
                 double q[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) q[k] = qs_s[k];
-                double r2a = 0.0, r2b = 0.0;
+                double acc = 0.0;
 #pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    const double da = xa[k].x - q[k], db = xa[k].y - q[k];
-                    r2a = fma(da, da, r2a);
-                    r2b = fma(db, db, r2b);
+                for (int j = 0; j < PPT; ++j) {
+                    double r2a = 0.0, r2b = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        const double da = xa[j][k].x - q[k], db = xa[j][k].y - q[k];
+                        r2a = fma(da, da, r2a);
+                        r2b = fma(db, db, r2b);
+                    }
+                    // same operation order as ens_half_kernel's lane (first pair by multiply, the rest by fma)
+                    acc = (j == 0) ? aa[j].x * exp(-0.5 * r2a) : fma(aa[j].x, exp(-0.5 * r2a), acc);
+                    acc = fma(aa[j].y, exp(-0.5 * r2b), acc);
                 }
-                double acc = aa.x * exp(-0.5 * r2a);
-                acc = fma(aa.y, exp(-0.5 * r2b), acc);
                 const double wsum = wave_sum_dpp(acc);
                 if ((tid & 63) == 63) scratch[tid >> 6] = wsum;
             }
@@ -465,6 +474,17 @@ ens_hist_copy_kernel(double* __restrict__ coords, double* __restrict__ logp, uns
     else *src = __longlong_as_double((long long)hist_row[i]);
 }
 
+// Does the training set fit the lanes' registers with this workgroup size?  (mirrors the dispatch below)
+bool ens_stream_fits(const alabi_ens* e) {
+    const int T = e->threads, half = e->gp->Npad / 2, db = dim_bucket(e->d);
+    const int ppt = (half + T - 1) / T;
+    if (T != 512 && T != 1024) return false;
+    if (ppt == 1) return db <= 24;
+    if (T == 512 && ppt == 2) return db <= 24;
+    if (T == 512 && ppt <= 4) return db <= 12;
+    return false;
+}
+
 int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
                       long long* n_accept, hipStream_t s) {
     alabi_gp* gp = e->gp;
@@ -479,7 +499,14 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
     a.K = K; a.W = e->W; a.n0 = n0; a.d = e->d; a.Npad = gp->Npad; a.thin_by = thin_by; a.spin_limit = 1 << 20;
     a.amp = exp(gp->log_amp); a.mean = gp->mean;
     const int db = dim_bucket(e->d);
-    ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(ens_stream_kernel<D>, dim3(n0, e->E), dim3(1024), 0, s, a));
+    // lanes x pairs-per-lane must cover Npad/2 point pairs; the classic kernel's lane->point map (and therefore its
+    // summation order) is reproduced exactly when T == e->threads.
+    const int T = e->threads;
+    const int ppt = (gp->Npad / 2 + T - 1) / T;
+    if (ppt == 1) { ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL((ens_stream_kernel<D, 1, 1024>), dim3(n0, e->E), dim3(T), 0, s, a)); }
+    else if (ppt == 2 && T <= 512) { ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL((ens_stream_kernel<D, 2, 512>), dim3(n0, e->E), dim3(T), 0, s, a)); }
+    else if (ppt <= 4 && T <= 512 && db <= 12) { ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL((ens_stream_kernel<D, 4, 512>), dim3(n0, e->E), dim3(T), 0, s, a)); }
+    else return ALABI_BAD_ARGUMENT;
     hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp,
                        e->hist + (size_t)K * WT * row, WT, e->d, 0);
     ALABI_LAUNCH_CHECK();

@@ -180,6 +180,9 @@ class EnsembleSampler:
             self.stream_fallbacks = getattr(self, "stream_fallbacks", 0) + 1
             st = _run()
         _lib.check(st, "alabi_ens_run")
+        path = C.c_int(0)
+        _lib.lib().alabi_ens_last_path(self._ens, C.byref(path))
+        self.last_path = "stream" if path.value == 1 else "launch-per-half-step"
         self._stream.synchronize()
         torch.cuda.current_stream().wait_stream(self._stream)
         self.last_run_seconds = time.perf_counter() - t0

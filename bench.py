@@ -171,7 +171,16 @@ def main():
         # dominant kernel = ens_half_kernel (2 launches per stretch-move step).  Algorithmic flops per launch:
         # (W/2) proposals x N training points x (2d + 2 flops + 1 exp counted as 1 flop).
         n_prop = (W * world if shard else W * args.ensembles) / 2.0 / (world if shard else 1)
-        flops_per_launch = n_prop * N * (2 * d + 3)
+        path = getattr(sampler, "last_path", "launch-per-half-step")
+        if path == "stream":
+            # persistent dataflow kernel: ONE launch covers up to 1024 whole steps (the draw-buffer chunk)
+            chunk = min(args.mcmc_steps, 1024)
+            launches_per_step = -(-args.mcmc_steps // chunk)
+            flops_per_launch = 2.0 * chunk * n_prop * N * (2 * d + 3)
+            kernel_name = f"ens_stream_kernel<{d},1,1024>"
+        else:
+            flops_per_launch = n_prop * N * (2 * d + 3)
+            kernel_name = f"ens_half_kernel<{d}>"
         us_per_launch = 1e3 * ev_ms / (args.steps * launches_per_step)
         achieved = flops_per_launch / (us_per_launch * 1e-6) / 1e12
         # HBM/fabric bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE, then
@@ -182,13 +191,19 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_by_kernel.json")
         if os.path.exists(pmc_path) and args.config == "C3" and args.ensembles == 1 and not shard:
             try:
-                pmc = json.load(open(pmc_path))["void alabi::ens_half_kernel<10>"]
-                traffic = (2.0 * pmc["FETCH_SIZE"]["mean_KB"] + pmc["WRITE_SIZE"]["mean_KB"]) * 1024.0
+                pmc = json.load(open(pmc_path))["void alabi::" + kernel_name.split("<")[0] + ("<10, 1, 1024>" if path == "stream" else "<10>")]
+                # FETCH_SIZE is doubled only where the reads are 16-B-per-lane streams (the per-launch X loads of
+                # ens_half_kernel); the persistent kernel's fetches are 8-byte polls / row reads, counted as reported
+                fetch_corr = 1.0 if path == "stream" else 2.0
+                traffic = (fetch_corr * pmc["FETCH_SIZE"]["mean_KB"] + pmc["WRITE_SIZE"]["mean_KB"]) * 1024.0
+                if path == "stream":   # the PMC pass profiled launches of `pmc_steps` steps: scale to this launch
+                    traffic *= min(args.mcmc_steps, 1024) / float(pmc.get("steps_per_launch", min(args.mcmc_steps, 1024)))
             except Exception:  # noqa: BLE001
                 traffic = None
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                           "kernel": "ens_half_kernel<10>", "us_per_launch_incl_boundary": us_per_launch,
+                           "kernel": kernel_name, "path": path, "us_per_launch_incl_boundary": us_per_launch,
+                           "us_per_half_step": 1e3 * ev_ms / (args.steps * 2 * args.mcmc_steps),
                            "flops_per_launch": flops_per_launch,
                            "note": "fp64 vector peak == fp64 matrix peak on MI355X; latency-bound kernel, see DESIGN.md"}
         out["acceptance_fraction"] = float(sampler.acceptance_fraction.mean()) if not shard else None
