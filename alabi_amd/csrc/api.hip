@@ -323,7 +323,11 @@ int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* 
         const char* env = getenv("ALABI_ENS_STREAM");
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            (long long)((W + 1) / 2) * n_ensembles <= n_cu && !(env && env[0] == '0')) {
+            n_ensembles <= n_cu && !(env && env[0] == '0')) {
+            // at most one workgroup per CU: G positions-in-flight per ensemble, each workgroup strides over the list
+            int G = n_cu / n_ensembles;
+            if (G > (W + 1) / 2) G = (W + 1) / 2;
+            e->stream_grid = G;
             const size_t hist_words = ((size_t)e->chunk_cap + 1) * WT * (d + 1);
             if (err == hipSuccess) err = hipMalloc(&e->hist, hist_words * sizeof(unsigned long long));
             if (err == hipSuccess) err = hipMalloc(&e->err, sizeof(int));

@@ -106,6 +106,7 @@ struct alabi_ens {
     // persistent dataflow path (ens_stream_kernel)
     unsigned long long* hist = nullptr;  // [(chunk_cap+1)][E*W][d+1] version history of every walker
     int* err = nullptr;                  // [1] spin time-out flag
+    int stream_grid = 0;                 // workgroups per ensemble of the persistent kernel
     int last_path = 0;                   // 1 if the last run used the persistent kernel
     int stream_ok = 0;                   // eligible: training set fits the lanes' registers, one workgroup per CU
 };

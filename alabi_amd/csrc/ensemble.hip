@@ -347,21 +347,35 @@ ens_stream_kernel(StreamArgs p) {
     if (tid == 0) ctl_s[1] = 0;
     __syncthreads();
 
+    // This workgroup's proposals: list positions b, b+G, b+2G, ... of every half step, in (step, split, position)
+    // order.  Every dependency points to an EARLIER half step, so the globally oldest unfinished proposal can always
+    // run: no deadlock as long as all G x E workgroups are resident.
+    const int G = gridDim.x;
+    auto next_item = [&](int& t, int& split, int& bb) {
+        bb += G;
+        for (;;) {
+            if (t >= p.K) return;
+            if (bb < (split ? p.W - p.n0 : p.n0)) return;
+            bb = b;
+            if (split == 0) split = 1; else { split = 0; ++t; }
+        }
+    };
     // proposal records are read one proposal ahead (they depend on nothing), so their latency is off the chain
     int n_w = 0, n_cw = 0;
     double n_zz = 0.0, n_lnfac = 0.0, n_lnu = 0.0;
-    auto fetch_record = [&](int t, int split) {
-        if (tid < 64 && t < p.K && b < (split ? p.W - p.n0 : p.n0)) {
-            const size_t pos = ((size_t)t * E + e) * p.W + (split ? p.n0 : 0) + b;
+    auto fetch_record = [&](int t, int split, int bb) {
+        if (tid < 64 && t < p.K) {
+            const size_t pos = ((size_t)t * E + e) * p.W + (split ? p.n0 : 0) + bb;
             n_w = p.rec.order[pos]; n_cw = p.rec.cw[pos];
             n_zz = p.rec.zz[pos]; n_lnfac = p.rec.lnfac[pos]; n_lnu = p.rec.lnu[pos];
         }
     };
-    fetch_record(0, 0);
-    for (int t = 0; t < p.K; ++t) {
-        for (int split = 0; split < 2; ++split) {
-            const int nS = split ? p.W - p.n0 : p.n0;
-            if (b >= nS) { fetch_record(split ? t + 1 : t, split ? 0 : 1); continue; }   // workgroup-uniform
+    int t = 0, split = 0, bb = b;          // b < G <= n0: the first item is valid
+    fetch_record(t, split, bb);
+    while (t < p.K) {
+        {
+            int t2 = t, s2 = split, b2 = bb;
+            next_item(t2, s2, b2);
             int w = 0;
             double qv = 0.0, sv = 0.0, lnfac = 0.0, lnu = 0.0;   // lane k < d: coordinate k; lane d: logp
             if (tid < 64) {                                           // wave 0 fetches the two rows it depends on
@@ -369,7 +383,7 @@ ens_stream_kernel(StreamArgs p) {
                 const int cw = n_cw;
                 const double zz = n_zz;
                 lnfac = n_lnfac; lnu = n_lnu;
-                fetch_record(split ? t + 1 : t, split ? 0 : 1);
+                fetch_record(t2, s2, b2);
                 // own row at version t, partner row at version t (+1 when the partner's half went first)
                 const unsigned long long* hw = p.hist + ((size_t)t * WT + w) * row;
                 const unsigned long long* hc = p.hist + ((size_t)(t + split) * WT + cw) * row;
@@ -453,6 +467,7 @@ ens_stream_kernel(StreamArgs p) {
                 }
                 if (tid == 0 && acc_flag && p.n_accept) atomicAdd(p.n_accept + w, 1ull);
             }
+            t = t2; split = s2; bb = b2;
         }
     }
 }
@@ -503,9 +518,9 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
     // summation order) is reproduced exactly when T == e->threads.
     const int T = e->threads;
     const int ppt = (gp->Npad / 2 + T - 1) / T;
-    if (ppt == 1) { ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL((ens_stream_kernel<D, 1, 1024>), dim3(n0, e->E), dim3(T), 0, s, a)); }
-    else if (ppt == 2 && T <= 512) { ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL((ens_stream_kernel<D, 2, 512>), dim3(n0, e->E), dim3(T), 0, s, a)); }
-    else if (ppt <= 4 && T <= 512 && db <= 12) { ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL((ens_stream_kernel<D, 4, 512>), dim3(n0, e->E), dim3(T), 0, s, a)); }
+    if (ppt == 1) { ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL((ens_stream_kernel<D, 1, 1024>), dim3(e->stream_grid, e->E), dim3(T), 0, s, a)); }
+    else if (ppt == 2 && T <= 512) { ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL((ens_stream_kernel<D, 2, 512>), dim3(e->stream_grid, e->E), dim3(T), 0, s, a)); }
+    else if (ppt <= 4 && T <= 512 && db <= 12) { ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL((ens_stream_kernel<D, 4, 512>), dim3(e->stream_grid, e->E), dim3(T), 0, s, a)); }
     else return ALABI_BAD_ARGUMENT;
     hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp,
                        e->hist + (size_t)K * WT * row, WT, e->d, 0);

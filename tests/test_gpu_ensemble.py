@@ -190,7 +190,8 @@ def test_stream_kernel_equals_launch_per_half_step(setup, monkeypatch):
     launch-per-half-step path produce bit-identical chains, acceptance counts and final states."""
     torch, g, o, y, bounds = setup
     from alabi_amd import EnsembleSampler
-    for W, E, nsteps, thin in ((40, 1, 300, 1), (33, 1, 130, 2), (24, 3, 90, 1)):
+    # the last two cases have more list positions than CUs per ensemble: each workgroup strides over several
+    for W, E, nsteps, thin in ((40, 1, 300, 1), (33, 1, 130, 2), (24, 3, 90, 1), (600, 1, 40, 1), (200, 3, 40, 1)):
         p0 = np.random.RandomState(W).uniform(-2, 2, (W * E, 5))
         monkeypatch.setenv("ALABI_ENS_STREAM", "1")
         a = EnsembleSampler(W, 5, g, y, bounds, seed=5, n_ensembles=E); sa = a.run_mcmc(p0, nsteps, thin_by=thin)
