@@ -71,6 +71,8 @@ int alabi_gp_create(int n_cap, int d, alabi_gp** out) {
     if (e == hipSuccess) e = hipMalloc(&gp->alpha, nc * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&gp->dinv, nc * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&gp->work, 2 * nc * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&gp->work2, nc * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&gp->flags, sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&gp->red, 4 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&gp->info, sizeof(int));
     if (e != hipSuccess) {
@@ -89,6 +91,8 @@ int alabi_gp_destroy(alabi_gp* gp) {
     if (gp->alpha) (void)hipFree(gp->alpha);
     if (gp->dinv) (void)hipFree(gp->dinv);
     if (gp->work) (void)hipFree(gp->work);
+    if (gp->work2) (void)hipFree(gp->work2);
+    if (gp->flags) (void)hipFree(gp->flags);
     if (gp->red) (void)hipFree(gp->red);
     if (gp->info) (void)hipFree(gp->info);
     if (gp->ws) (void)hipFree(gp->ws);

@@ -59,6 +59,8 @@ struct alabi_gp {
     double* alpha = nullptr;  // [n_cap]
     double* dinv = nullptr;   // [n_cap] 1 / L_ii (every triangular solve multiplies by it)
     double* work = nullptr;   // [2 * n_cap] solve scratch
+    double* work2 = nullptr;  // [n_cap] hand-off buffer of the dataflow solve
+    int* flags = nullptr;     // [1] time-out flag of the dataflow solve
     double* red = nullptr;    // [4] reductions (logdet, r.alpha)
     int* info = nullptr;      // [1] Cholesky info (0 ok, else 1-based pivot)
     double* ws = nullptr;     // predict-variance workspace

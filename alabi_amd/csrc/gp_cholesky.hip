@@ -23,6 +23,39 @@ namespace alabi {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// One fp64 MFMA rank-16 update of a 16x16 tile held in LDS:  C -= P Q^T, with P = rows pr.. and Q = rows qr.. of the
+// same 16-column slab (columns c0..c0+15) of `M`.  One wavefront; lane l: A[m=l&15][k=l>>4], B[k=l>>4][n=l&15],
+// C/D row (l>>4)+4i, column l&15.
+__device__ inline void tile_update_16(double (*C)[65], int cr, int cc, double (*Pm)[65], int pr, double (*Qm)[65], int qr,
+                                      int c0, int lane) {
+    const int lr = lane & 15, lk = lane >> 4;
+    v4f64 acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = C[cr + lk + 4 * i][cc + lr];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const double a = -Pm[pr + lr][c0 + 4 * kk + lk];
+        const double b = Qm[qr + lr][c0 + 4 * kk + lk];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) C[cr + lk + 4 * i][cc + lr] = acc[i];
+}
+
+// 1/sqrt(piv) from the hardware estimate + two Newton steps, L_jj = piv * rinv with one correction, then the
+// reciprocal refined: ~12 dependent ops instead of an IEEE sqrt followed by an IEEE division.
+__device__ inline void pivot_factors(double piv, double& ljj, double& rinv) {
+    rinv = __builtin_amdgcn_rsq(piv);
+    rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+    rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+    ljj = piv * rinv;
+    ljj = fma(0.5 * rinv, fma(-ljj, ljj, piv), ljj);
+    rinv = fma(rinv, fma(-ljj, rinv, 1.0), rinv);
+}
+
+// Diagonal block: ONE wavefront, 16-column slabs.  Inside a slab every lane (= row) runs the left-looking column
+// recurrence (dot products of length <= 15 against LDS broadcasts, one rsqrt chain per column); after a slab the
+// trailing tiles get its rank-16 update on the matrix cores.  No workgroup barrier, 64 pivots in sequence.
 __global__ void __launch_bounds__(64)
 potrf_diag_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info, double* __restrict__ dinv) {
     __shared__ double Ls[64][65];
@@ -30,78 +63,96 @@ potrf_diag_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info
     double* Ab = A + (size_t)(kb * 64) * ld + kb * 64;
     for (int r = 0; r < 64; ++r) Ls[r][lane] = Ab[(size_t)r * ld + lane];   // coalesced rows
     __syncthreads();
-    double a[64];
-#pragma unroll
-    for (int k = 0; k < 64; ++k) a[k] = Ls[lane][k];   // lane i <- row i (stride 65: conflict-free)
-    __syncthreads();
     double my_rinv = 1.0;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        // v_i = A_ij - sum_{k<j} L_ik L_jk ; L_jk is row j, published in LDS at earlier columns
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int s = 0; s < 4; ++s) {
+        const int c0 = 16 * s;
+        double a[16];
 #pragma unroll
-        for (int k = 0; k < j; ++k) {
-            const double ljk = Ls[j][k];
-            if ((k & 3) == 0) s0 = fma(a[k], ljk, s0);
-            else if ((k & 3) == 1) s1 = fma(a[k], ljk, s1);
-            else if ((k & 3) == 2) s2 = fma(a[k], ljk, s2);
-            else s3 = fma(a[k], ljk, s3);
+        for (int j = 0; j < 16; ++j) a[j] = Ls[lane][c0 + j];      // row `lane`, this slab (rows < c0 carry unused values)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < j; ++k) {
+                const double ljk = Ls[c0 + j][c0 + k];
+                if (k & 1) s1 = fma(a[k], ljk, s1); else s0 = fma(a[k], ljk, s0);
+            }
+            const double v = a[j] - (s0 + s1);
+            double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), c0 + j),
+                                          __builtin_amdgcn_readlane(__double2loint(v), c0 + j));
+            if (!(piv > 0.0)) {  // also true for NaN
+                if (lane == 0) atomicCAS(info, 0, kb * 64 + c0 + j + 1);
+                piv = 1.0;
+            }
+            double ljj, rinv;
+            pivot_factors(piv, ljj, rinv);
+            a[j] = (lane == c0 + j) ? ljj : v * rinv;
+            if (lane == c0 + j) my_rinv = rinv;
+            Ls[lane][c0 + j] = a[j];
+            __syncthreads();             // single wave: orders the LDS write before the next column's broadcasts
         }
-        const double v = a[j] - ((s0 + s1) + (s2 + s3));
-        // pivot = v of lane j
-        double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j),
-                                      __builtin_amdgcn_readlane(__double2loint(v), j));
-        if (!(piv > 0.0)) {  // also true for NaN
-            if (lane == 0) atomicCAS(info, 0, kb * 64 + j + 1);
-            piv = 1.0;
-        }
-        // 1/sqrt(piv) from the hardware estimate + two Newton steps (full fp64), then L_jj = piv * rinv with
-        // one correction step: ~12 dependent ops instead of an IEEE sqrt followed by an IEEE division.
-        double rinv = __builtin_amdgcn_rsq(piv);
-        rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
-        rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
-        double ljj = piv * rinv;
-        ljj = fma(0.5 * rinv, fma(-ljj, ljj, piv), ljj);
-        rinv = fma(rinv, fma(-ljj, rinv, 1.0), rinv);   // rinv = 1 / L_jj to working precision
-        a[j] = (lane == j) ? ljj : v * rinv;
-        if (lane == j) my_rinv = rinv;
-        Ls[lane][j] = a[j];          // rows >= j are final in column j (rows < j write unused upper entries)
-        __syncthreads();             // single wave: orders the LDS write before the next column's reads
+        // rank-16 update of the tiles right of / below the slab (lower triangle of the 16x16 tile grid)
+#pragma unroll
+        for (int ti = s + 1; ti < 4; ++ti)
+#pragma unroll
+            for (int tk = s + 1; tk <= ti; ++tk) tile_update_16(Ls, 16 * ti, 16 * tk, Ls, 16 * ti, Ls, 16 * tk, c0, lane);
+        __syncthreads();
     }
     dinv[kb * 64 + lane] = my_rinv;
     for (int r = 0; r < 64; ++r)
         if (lane <= r) Ab[(size_t)r * ld + lane] = Ls[r][lane];
 }
 
-// X * L_kk^T = B for 64 rows: lane = row, serial along the row, no cross-lane traffic.
-__global__ void __launch_bounds__(64)
+// X * L_kk^T = B for 64 rows; four wavefronts, wave w owns rows 16w..16w+15.  16-column slabs: inside a slab one lane
+// runs one row's recurrence (L_kk read from LDS as broadcasts, divisions are multiplications by dinv, no cross-lane
+// traffic); the slab's effect on the remaining columns is a rank-16 update on the matrix cores, one row tile per wave.
+__global__ void __launch_bounds__(256)
 trsm_panel_kernel(double* __restrict__ A, int ld, int kb, const double* __restrict__ dinv) {
     __shared__ double lkk[64][65];
     __shared__ double bs[64][65];
     __shared__ double di[64];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const double* Lb = A + (size_t)(kb * 64) * ld + kb * 64;
     double* Bb = A + (size_t)((kb + 1 + blockIdx.x) * 64) * ld + kb * 64;
-    for (int r = 0; r < 64; ++r) {
-        lkk[r][lane] = Lb[(size_t)r * ld + lane];
-        bs[r][lane] = Bb[(size_t)r * ld + lane];
+    for (int e = tid; e < 4096; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        lkk[r][c] = Lb[(size_t)r * ld + c];
+        bs[r][c] = Bb[(size_t)r * ld + c];
     }
-    di[lane] = dinv[kb * 64 + lane];
+    if (tid < 64) di[tid] = dinv[kb * 64 + tid];
     __syncthreads();
-    double b[64];
+    const int row = 16 * w + (lane & 15);
 #pragma unroll
-    for (int c = 0; c < 64; ++c) b[c] = bs[lane][c];
+    for (int s = 0; s < 4; ++s) {
+        const int c0 = 16 * s;
+        if (lane < 16) {
+            double b[16];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) {
-        const double x = b[c] * di[c];
-        b[c] = x;
+            for (int j = 0; j < 16; ++j) b[j] = bs[row][c0 + j];
 #pragma unroll
-        for (int c2 = c + 1; c2 < 64; ++c2) b[c2] = fma(-x, lkk[c2][c], b[c2]);
+            for (int j = 0; j < 16; ++j) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < j; ++k) {
+                    const double ljk = lkk[c0 + j][c0 + k];
+                    if (k & 1) s1 = fma(b[k], ljk, s1); else s0 = fma(b[k], ljk, s0);
+                }
+                b[j] = (b[j] - (s0 + s1)) * di[c0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bs[row][c0 + j] = b[j];
+        }
+        __syncthreads();
+        // B[rows of this wave, later slabs] -= X_s * L_kk[later rows, slab]^T
+#pragma unroll
+        for (int t = s + 1; t < 4; ++t) tile_update_16(bs, 16 * w, 16 * t, bs, 16 * w, lkk, 16 * t, c0, lane);
+        __syncthreads();
     }
-#pragma unroll
-    for (int c = 0; c < 64; ++c) bs[lane][c] = b[c];
-    __syncthreads();
-    for (int r = 0; r < 64; ++r) Bb[(size_t)r * ld + lane] = bs[r][lane];
+    for (int e = tid; e < 4096; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        Bb[(size_t)r * ld + c] = bs[r][c];
+    }
 }
 
 // C[bi,bj] -= P[bi] * P[bj]^T with P[b] = A[b-block rows, kb-block cols].
@@ -154,7 +205,7 @@ int launch_cholesky(alabi_gp* gp, hipStream_t s) {
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, s, gp->L, ld, kb, gp->info, gp->dinv);
         int T = nb - kb - 1;
         if (T > 0) {
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(64), 0, s, gp->L, ld, kb, gp->dinv);
+            hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(256), 0, s, gp->L, ld, kb, gp->dinv);
             hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, s, gp->L, ld, kb);
         }
     }

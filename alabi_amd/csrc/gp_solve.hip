@@ -9,6 +9,8 @@
 // diagonal system in one wavefront (lane i holds row i, the solved entry is broadcast with
 // a wave shuffle) and then applies its own 64x64 block of the update, so a step is ONE
 // kernel and the steps are ordered by the stream.  2 N^2 flops, latency bound: once per refit.
+#include <cstdlib>
+
 #include "gp_device.hpp"
 
 namespace alabi {
@@ -94,6 +96,122 @@ trsv_bwd_step_kernel(const double* __restrict__ L, int ld, int kb, const double*
     if (tid < 64) z[i * 64 + tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Single-launch dataflow solve.  Workgroup i owns block row i.  Forward: it folds L[i,k] z_k into its right-hand side
+// as soon as z_k appears (k ascending), solves its diagonal block and publishes z_i; backward: the same with
+// L[k,i]^T alpha_k for k descending.  z and alpha are handed over through buffers pre-filled with a sentinel NaN:
+// every word is one aligned 8-byte write-through (sc1) store and the consumer polls the words themselves with sc1
+// loads -- the data is the flag (cdna_hip_programming.md Guideline 16, R2).  The dependency graph is acyclic
+// (fwd(i) <- fwd(k<i); bwd(i) <- fwd(i), bwd(k>i)) and nb <= 157 workgroups are all resident, so there is no deadlock;
+// every spin is bounded and a time-out makes all workgroups leave (the host then runs the per-step kernels).
+// Critical path: nb x (64-step diagonal solve + one hand-off) per sweep instead of nb kernel launches.
+#define ALABI_TRSV_EMPTY 0x7FF8A1AB1D15EA5Eull
+
+__device__ inline bool trsv_wait_block(const unsigned long long* src, double* dst_lds, int* err, int spin_limit, int lane) {
+    unsigned long long v = ALABI_TRSV_EMPTY;
+    int spins = 0;
+    bool ok = true;
+    while (true) {
+        if (v == ALABI_TRSV_EMPTY) v = __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v != ALABI_TRSV_EMPTY)) break;
+        if (++spins > spin_limit ||
+            ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (ok) dst_lds[lane] = __longlong_as_double((long long)v);
+    else if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ok;
+}
+
+__global__ void __launch_bounds__(256)
+trsv_stream_kernel(const double* __restrict__ L, int ld, int nb, const double* __restrict__ dinv,
+                   const double* __restrict__ r, unsigned long long* __restrict__ zbuf,
+                   unsigned long long* __restrict__ abuf, double* __restrict__ alpha, int* __restrict__ err, int spin_limit) {
+    __shared__ double lkk[64][65];
+    __shared__ double xs[64];        // the z_k / alpha_k block being folded in
+    __shared__ double rhs[64];
+    __shared__ double part[4][64];
+    __shared__ int abort_s;
+    const int tid = threadIdx.x, i = blockIdx.x;
+    const double* Lb = L + (size_t)(i * 64) * ld + i * 64;
+    for (int e = tid; e < 4096; e += 256) {
+        int rr = e >> 6, c = e & 63;
+        lkk[rr][c] = (c <= rr) ? Lb[(size_t)rr * ld + c] : 0.0;
+    }
+    if (tid == 0) abort_s = 0;
+    const double di = (tid < 64) ? dinv[i * 64 + tid] : 0.0;
+    __syncthreads();
+    // ---------------- forward: rhs_i = r_i - sum_{k<i} L[i,k] z_k ; thread = (row, quarter of the 64 columns)
+    {
+        const int row = tid >> 2, q = tid & 3;
+        double acc = 0.0;
+        for (int k = 0; k < i; ++k) {
+            const double* Lrow = L + (size_t)(i * 64 + row) * ld + k * 64 + q * 16;
+            double lv[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lv[c] = Lrow[c];            // issued before the wait: latency hidden
+            if (tid < 64 && !trsv_wait_block(zbuf + k * 64, xs, err, spin_limit, tid)) abort_s = 1;
+            __syncthreads();
+            if (abort_s) return;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc = fma(lv[c], xs[q * 16 + c], acc);
+            __syncthreads();                                         // xs is overwritten by the next block
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (q == 0) rhs[row] = r[i * 64 + row] - acc;
+    }
+    __syncthreads();
+    double zi = 0.0;   // lane j of wave 0 keeps z_i[j]
+    if (tid < 64) {
+        double v = rhs[tid];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const double zj = lane_bcast(v * di, j);
+            if (tid == j) v = zj;
+            if (tid > j) v = fma(-lkk[tid][j], zj, v);
+        }
+        zi = v;
+        __hip_atomic_store(zbuf + i * 64 + tid, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---------------- backward: alpha_i = L_ii^-T (z_i - sum_{k>i} L[k,i]^T alpha_k); lanes run along the row index
+    {
+        const int rr = tid & 63, q = tid >> 6;
+        double acc = 0.0;
+        for (int k = nb - 1; k > i; --k) {
+            const double* Lc = L + (size_t)(k * 64 + q * 16) * ld + i * 64 + rr;
+            double lv[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lv[c] = Lc[(size_t)c * ld];
+            if (tid < 64 && !trsv_wait_block(abuf + k * 64, xs, err, spin_limit, tid)) abort_s = 1;
+            __syncthreads();
+            if (abort_s) return;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc = fma(lv[c], xs[q * 16 + c], acc);
+            __syncthreads();
+        }
+        part[q][rr] = acc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double v = zi - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+#pragma unroll
+        for (int j = 63; j >= 0; --j) {
+            const double aj = lane_bcast(v * di, j);
+            if (tid == j) v = aj;
+            if (tid < j) v = fma(-lkk[j][tid], aj, v);
+        }
+        __hip_atomic_store(abuf + i * 64 + tid, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        alpha[i * 64 + tid] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+trsv_fill_kernel(unsigned long long* __restrict__ a, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) a[i] = ALABI_TRSV_EMPTY;
+}
+
 __global__ void __launch_bounds__(256)
 residual_kernel(const double* __restrict__ y, int N, int Npad, double mean, double* __restrict__ r) {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,6 +245,24 @@ int launch_alpha(alabi_gp* gp, hipStream_t s) {
     double* z = gp->work + gp->n_cap;  // [Npad] forward solution, consumed by the backward sweep
     hipLaunchKernelGGL(residual_kernel, dim3((gp->Npad + 255) / 256), dim3(256), 0, s, gp->y, gp->N,
                        gp->Npad, gp->mean, r);
+    const char* env = getenv("ALABI_TRSV_STREAM");
+    if (nb <= 200 && gp->flags && !(env && env[0] == '0')) {
+        // single-launch dataflow solve (all nb workgroups resident); z / alpha hand-off buffers live in `work`
+        unsigned long long* zbuf = reinterpret_cast<unsigned long long*>(z);
+        unsigned long long* abuf = reinterpret_cast<unsigned long long*>(gp->work2);
+        ALABI_HIP_CHECK(hipMemsetAsync(gp->flags, 0, sizeof(int), s));
+        hipLaunchKernelGGL(trsv_fill_kernel, dim3((gp->Npad + 255) / 256), dim3(256), 0, s, zbuf, gp->Npad);
+        hipLaunchKernelGGL(trsv_fill_kernel, dim3((gp->Npad + 255) / 256), dim3(256), 0, s, abuf, gp->Npad);
+        hipLaunchKernelGGL(trsv_stream_kernel, dim3(nb), dim3(256), 0, s, gp->L, ld, nb, gp->dinv, r, zbuf, abuf, gp->alpha,
+                           gp->flags, 1 << 20);
+        ALABI_LAUNCH_CHECK();
+        int flag = 0;
+        ALABI_HIP_CHECK(hipMemcpyAsync(&flag, gp->flags, sizeof(int), hipMemcpyDeviceToHost, s));
+        ALABI_HIP_CHECK(hipStreamSynchronize(s));
+        if (!flag) return ALABI_OK;
+        // timed out (workgroups not co-resident?): fall through to the launch-per-step kernels
+        hipLaunchKernelGGL(residual_kernel, dim3((gp->Npad + 255) / 256), dim3(256), 0, s, gp->y, gp->N, gp->Npad, gp->mean, r);
+    }
     for (int kb = 0; kb < nb; ++kb)
         hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(nb - kb), dim3(256), 0, s, gp->L, ld, kb, gp->dinv, r, z);
     for (int kb = nb - 1; kb >= 0; --kb)
