@@ -87,9 +87,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # ALABI_DIST_BACKEND=gloo is a TEST rig (several ranks on one GPU, which RCCL refuses); the driver's runs use nccl
+    backend = os.environ.get("ALABI_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     cfg = make_config(args.config, N=args.ntrain, W=args.walkers)
     h = cfg["hyper"]
@@ -152,10 +158,34 @@ def main():
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     value = samples_per_step * args.steps / dt
+
+    # Secondary measurement on N > 1 GPUs (every rank takes part): ONE ensemble of 256*N walkers sharded over the ranks
+    # with an RCCL all-gather of the updated half after every half step (alabi_amd/dist.py).  Reported next to the
+    # replica number; never the headline value.
+    shard_info = None
+    if world > 1 and not shard and not args.no_extras:
+        try:
+            from alabi_amd.dist import HipBackend, ShardedEnsemble
+            Wtot = W * world
+            p0s = np.random.RandomState(5).uniform(cfg["bounds"][:, 0] * 0.5, cfg["bounds"][:, 1] * 0.5, (Wtot, d))
+            s2 = EnsembleSampler(Wtot, d, gp, cfg["y"], cfg["bounds"], seed=99)
+            ens2 = ShardedEnsemble(HipBackend(s2))
+            c0 = torch.as_tensor(p0s, device="cuda")
+            ens2.run(c0, 8, store=False)
+            fence()
+            t1 = time.perf_counter()
+            nst = 128
+            ens2.run(c0, nst, store=True)
+            fence()
+            dt2 = time.perf_counter() - t1
+            shard_info = {"walkers": Wtot, "steps": nst, "samples_per_s": Wtot * nst / dt2,
+                          "us_per_half_step": 1e6 * dt2 / (2 * nst), "collective": "all_gather_into_tensor per half step"}
+        except Exception as ex:  # noqa: BLE001
+            shard_info = {"error": repr(ex)[:300]}
 
     out = {
         "metric": "surrogate_mcmc_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world,
@@ -228,6 +258,8 @@ def main():
                 torch.cuda.synchronize()
                 extras[label] = M * reps / (time.perf_counter() - t1)
             out["extras"] = extras
+        if shard_info is not None:
+            out["sharded_ensemble"] = shard_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
