@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libalabi_hip.so")
 
 OK, NOT_PD, BAD_ARG, HIP_ERROR, NOT_COMPUTED, TIMEOUT = 0, 1, 2, 3, 4, 5
 UTILITY_CODES = {"bape": 0, "agp": 1, "jones": 2}
+KERNEL_CODES = {"ExpSquaredKernel": 0, "Matern32Kernel": 1, "Matern52Kernel": 2, "RationalQuadraticKernel": 3}
 MAX_DIM = 64
 
 _vp, _i, _ll, _d = C.c_void_p, C.c_int, C.c_longlong, C.c_double
@@ -33,6 +34,7 @@ SIGNATURES = {
     "alabi_gp_create": (_i, [_i, _i, C.POINTER(_vp)]),
     "alabi_gp_destroy": (_i, [_vp]),
     "alabi_gp_set_hyper": (_i, [_vp, _d, _d, _d, _pd]),
+    "alabi_gp_set_kernel": (_i, [_vp, _i, _d]),
     "alabi_gp_compute": (_i, [_vp, _vp, _i, _vp]),
     "alabi_gp_last_pivot": (_i, [_vp, _pi]),
     "alabi_gp_set_y": (_i, [_vp, _vp, _vp]),
@@ -42,7 +44,7 @@ SIGNATURES = {
     "alabi_gp_get_alpha": (_i, [_vp, _vp, _vp]),
     "alabi_gp_get_factor": (_i, [_vp, _vp, _vp]),
     "alabi_gp_n": (_i, [_vp, _pi]),
-    "alabi_kernel_matrix": (_i, [_vp, _i, _vp, _i, _i, _d, _pd, _vp, _vp]),
+    "alabi_kernel_matrix": (_i, [_vp, _i, _vp, _i, _i, _i, _d, _d, _pd, _vp, _vp]),
     "alabi_utility_scan": (_i, [_vp, _i, _vp, _ll, _pd, _d, _vp, _vp, _vp, _pd, _pll, _vp]),
     "alabi_utility_eval": (_i, [_i, _vp, _ll, _i, _pd, _d, _vp, _vp, _vp, _vp]),
     "alabi_ens_create": (_i, [_vp, _i, _i, _i, _pd, _ull, C.POINTER(_vp)]),

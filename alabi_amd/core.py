@@ -229,6 +229,9 @@ class SurrogateModel(object):
             hp[pnames.index(f"{self.kernel_amp_key}:log_constant")] = [v * 10 ** self.gp_amp_rng[0], v * 10 ** self.gp_amp_rng[1]]
         if self.fit_white_noise:
             hp[pnames.index("white_noise:value")] = [self.white_noise - 3, self.white_noise + 3]
+        for ii, name in enumerate(pnames):       # RationalQuadraticKernel's shape parameter (the reference leaves it unbounded)
+            if name.endswith(":log_alpha"):
+                hp[ii] = [-3.0, 3.0]
         if self.uniform_scales:
             hp[pnames.index(f"{self.kernel_scale_key}:metric:log_M")] = list(self.gp_scale_rng)
         else:
@@ -282,9 +285,6 @@ class SurrogateModel(object):
         if kernel not in _KERNELS:
             raise ValueError(f"Kernel '{kernel}' is not a valid option. Valid options: ExpSquaredKernel, "
                              "Matern32Kernel, Matern52Kernel, RationalQuadraticKernel")
-        if kernel != "ExpSquaredKernel":
-            raise NotImplementedError(f"{kernel}: only ExpSquaredKernel has a HIP implementation so far "
-                                      "(SURVEY.md section 8(f) #4)")
         self.fit_amp, self.fit_mean, self.fit_white_noise = fit_amp, fit_mean, fit_white_noise
         self.white_noise = white_noise
         self.uniform_scales = uniform_scales
@@ -315,7 +315,7 @@ class SurrogateModel(object):
         gp = None
         for attempt in range(1, 11):  # reference: up to 10 random initial length scales (core.py:980-1048)
             log_ls = self._rng.uniform(min(gp_scale_rng), max(gp_scale_rng), self.ndim)
-            self.kernel = {"name": kernel, "log_M": log_ls.copy(), "log_constant": 0.0}
+            self.kernel = {"name": kernel, "log_M": log_ls.copy(), "log_constant": 0.0, "log_alpha": 1.0}
             gp = gp_utils.configure_gp(self._theta, self._y, self.kernel, fit_amp=fit_amp, fit_mean=fit_mean,
                                        fit_white_noise=fit_white_noise, white_noise=white_noise)
             if gp is not None:
@@ -357,7 +357,8 @@ class SurrogateModel(object):
     def _new_gp(self, _y):
         log_const = np.log(np.var(_y) / self.ndim) if self.fit_amp else self.kernel.get("log_constant", 0.0)
         return HipGP(self.ndim, mean=np.median(_y), white_noise=self.white_noise, log_constant=log_const,
-                     log_M=self.kernel["log_M"], fit_mean=self.fit_mean, fit_white_noise=self.fit_white_noise)
+                     log_M=self.kernel["log_M"], fit_mean=self.fit_mean, fit_white_noise=self.fit_white_noise,
+                     kernel=self.kernel.get("name", "ExpSquaredKernel"), log_alpha=self.kernel.get("log_alpha", 1.0))
 
     def _fit_gp(self, _theta=None, _y=None, hyperparameters=None):
         """New GP on (_theta, _y) with the carried hyper-parameter vector, factorised (core.py:1097-1160)."""

@@ -112,6 +112,14 @@ int alabi_gp_set_hyper(alabi_gp* gp, double mean, double log_white_noise, double
     return ALABI_OK;
 }
 
+int alabi_gp_set_kernel(alabi_gp* gp, int kernel_type, double log_alpha) {
+    if (!gp || kernel_type < 0 || kernel_type > 3 || !std::isfinite(log_alpha)) return ALABI_BAD_ARGUMENT;
+    gp->kf.type = kernel_type;
+    gp->kf.alpha = std::exp(log_alpha);
+    gp->computed = false; gp->has_alpha = false; gp->gen++;
+    return ALABI_OK;
+}
+
 int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream) {
     if (!gp || !X || N <= 0 || N > gp->n_cap) return ALABI_BAD_ARGUMENT;
     hipStream_t s = as_stream(stream);
@@ -208,12 +216,15 @@ int alabi_gp_get_factor(alabi_gp* gp, double* L_out, void* stream) {
     return ALABI_OK;
 }
 
-int alabi_kernel_matrix(const double* X1, int n1, const double* X2, int n2, int d, double log_amp,
-                        const double* log_M, double* K_out, void* stream) {
-    if (!X1 || !X2 || !K_out || !log_M || n1 <= 0 || n2 <= 0 || d <= 0 || d > ALABI_MAX_DIM) return ALABI_BAD_ARGUMENT;
+int alabi_kernel_matrix(const double* X1, int n1, const double* X2, int n2, int d, int kernel_type, double log_alpha,
+                        double log_amp, const double* log_M, double* K_out, void* stream) {
+    if (!X1 || !X2 || !K_out || !log_M || n1 <= 0 || n2 <= 0 || d <= 0 || d > ALABI_MAX_DIM || kernel_type < 0 ||
+        kernel_type > 3)
+        return ALABI_BAD_ARGUMENT;
+    const KernelFn kf{kernel_type, std::exp(log_alpha)};
     DimVec inv;
     for (int k = 0; k < ALABI_MAX_DIM; ++k) inv.v[k] = (k < d) ? std::exp(-0.5 * log_M[k]) : 0.0;
-    return launch_kernel_matrix(X1, n1, X2, n2, d, std::exp(log_amp), inv, K_out, as_stream(stream));
+    return launch_kernel_matrix(X1, n1, X2, n2, d, std::exp(log_amp), inv, kf, K_out, as_stream(stream));
 }
 
 // ----------------------------------------------------------------------------- utility
@@ -399,7 +410,7 @@ static HalfArgs base_args(alabi_ens* e, double* coords, double* logp) {
     alabi_gp* gp = e->gp;
     h.coords = coords; h.logp = logp; h.consts = e->consts;
     h.Xt = gp->Xt; h.alpha = gp->alpha; h.Npad = gp->Npad;
-    h.amp = std::exp(gp->log_amp); h.mean = gp->mean;
+    h.amp = std::exp(gp->log_amp); h.mean = gp->mean; h.kf = gp->kf;
     h.W = e->W; h.d = e->d; h.n0 = (e->W + 1) / 2;
     h.thin_by = 1; h.run_state = e->run_state;
     return h;

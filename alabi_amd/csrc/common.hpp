@@ -36,6 +36,15 @@ struct DimVec {
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Radial part of the stationary kernel: k(x,x') = amp * f(r2), r2 = sum_k (x_k - x'_k)^2 / M_k.
+//   0 ExpSquaredKernel exp(-r2/2)              1 Matern32Kernel (1 + s) exp(-s), s = sqrt(3 r2)
+//   2 Matern52Kernel (1 + s + s^2/3) exp(-s), s = sqrt(5 r2)     3 RationalQuadraticKernel (1 + r2/(2a))^-a
+// (george kernel definitions; reference: alabi/core.py:1000-1014)
+struct KernelFn {
+    int type;
+    double alpha;
+};
+
 }  // namespace alabi
 
 // ---- handle layouts ------------------------------------------------------------------
@@ -50,6 +59,7 @@ struct alabi_gp {
     int last_pivot = 0;
     // hyper-parameters (host copies)
     double mean = 0.0, log_wn = -12.0, log_amp = 0.0;
+    alabi::KernelFn kf{0, 1.0};   // kernel family (+ alpha of the rational quadratic)
     double log_M[ALABI_MAX_DIM];
     alabi::DimVec inv_len;  // exp(-0.5 log_M): coordinates are pre-multiplied by it
     // device buffers
@@ -118,7 +128,7 @@ namespace alabi {
 int launch_prepare_inputs(alabi_gp* gp, const double* X, int N, hipStream_t s);
 int launch_assemble(alabi_gp* gp, hipStream_t s);
 int launch_kernel_matrix(const double* X1, int n1, const double* X2, int n2, int d, double amp,
-                         const DimVec& inv_len, double* K, hipStream_t s);
+                         const DimVec& inv_len, KernelFn kf, double* K, hipStream_t s);
 // gp_cholesky.hip
 int launch_cholesky(alabi_gp* gp, hipStream_t s);
 // gp_solve.hip
@@ -148,6 +158,7 @@ struct HalfArgs {
     const long long* run_state;  // [0] chunk's first global step, [1] steps done before the chunk
     int n0, W, d, Npad, split, part_begin, local_t, thin_by;
     double amp, mean;
+    KernelFn kf;
 };
 int launch_ens_draw(alabi_ens* e, int nsteps, double a, hipStream_t s);
 int launch_ens_prep(alabi_ens* e, const int* order, int n0, const double* u_z, const int* partner,

@@ -148,7 +148,7 @@ ens_prep_kernel(const int* __restrict__ order, int n0, int W, const double* __re
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-template <int D>
+template <int D, bool GENERIC>
 __global__ void __launch_bounds__(1024)
 ens_half_kernel(HalfArgs p) {
     __shared__ double q_s[ALABI_MAX_DIM], qs_s[ALABI_MAX_DIM], old_s[ALABI_MAX_DIM];
@@ -203,8 +203,8 @@ ens_half_kernel(HalfArgs p) {
             r2a = fma(da, da, r2a);
             r2b = fma(db, db, r2b);
         }
-        double acc = aa.x * exp(-0.5 * r2a);
-        acc = fma(aa.y, exp(-0.5 * r2b), acc);
+        double acc = aa.x * radial<GENERIC>(r2a, p.kf);
+        acc = fma(aa.y, radial<GENERIC>(r2b, p.kf), acc);
         for (int j = tid + T; j < half; j += T) {
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -215,8 +215,8 @@ ens_half_kernel(HalfArgs p) {
                 s1 = fma(d1, d1, s1);
             }
             const f64x2 al = reinterpret_cast<const f64x2*>(p.alpha)[j];
-            acc = fma(al.x, exp(-0.5 * s0), acc);
-            acc = fma(al.y, exp(-0.5 * s1), acc);
+            acc = fma(al.x, radial<GENERIC>(s0, p.kf), acc);
+            acc = fma(al.y, radial<GENERIC>(s1, p.kf), acc);
         }
         // (3) wave totals by DPP, one LDS word per wave, ONE barrier; only wave 0 goes on
         const double wsum = wave_sum_dpp(acc);
@@ -256,7 +256,7 @@ ens_half_kernel(HalfArgs p) {
 template <int D>
 __global__ void __launch_bounds__(1024)
 ens_lnprob_kernel(const double* __restrict__ coords, int d, const double* __restrict__ Xt,
-                  const double* __restrict__ alpha, int Npad, double amp, double mean,
+                  const double* __restrict__ alpha, int Npad, double amp, double mean, KernelFn kf,
                   const double* __restrict__ consts, double* __restrict__ logp) {
     __shared__ double qs_s[ALABI_MAX_DIM];
     __shared__ double scratch[16];
@@ -273,7 +273,7 @@ ens_lnprob_kernel(const double* __restrict__ coords, int d, const double* __rest
     }
     const int inb = __syncthreads_and(ok);
     double lp = -INFINITY;
-    if (inb) lp = fma(amp, gp_kernel_dot_block<D>(Xt, alpha, Npad, qs_s, scratch), mean);
+    if (inb) lp = fma(amp, gp_kernel_dot_block<D>(Xt, alpha, Npad, qs_s, scratch, kf), mean);
     if (tid == 0) logp[w] = lp;
 }
 
@@ -311,6 +311,7 @@ struct StreamArgs {
     const long long* run_state;
     int K, W, n0, d, Npad, thin_by, spin_limit;
     double amp, mean;
+    KernelFn kf;
 };
 
 __device__ inline unsigned long long ld_sc1(const unsigned long long* p) {
@@ -320,7 +321,7 @@ __device__ inline void st_sc1(unsigned long long* p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int D, int PPT, int TMAX>
+template <int D, int PPT, int TMAX, bool GENERIC>
 __global__ void __launch_bounds__(TMAX)
 ens_stream_kernel(StreamArgs p) {
     __shared__ double qs_s[ALABI_MAX_DIM];
@@ -438,8 +439,8 @@ ens_stream_kernel(StreamArgs p) {
                         r2b = fma(db, db, r2b);
                     }
                     // same operation order as ens_half_kernel's lane (first pair by multiply, the rest by fma)
-                    acc = (j == 0) ? aa[j].x * exp(-0.5 * r2a) : fma(aa[j].x, exp(-0.5 * r2a), acc);
-                    acc = fma(aa[j].y, exp(-0.5 * r2b), acc);
+                    acc = (j == 0) ? aa[j].x * radial<GENERIC>(r2a, p.kf) : fma(aa[j].x, radial<GENERIC>(r2a, p.kf), acc);
+                    acc = fma(aa[j].y, radial<GENERIC>(r2b, p.kf), acc);
                 }
                 const double wsum = wave_sum_dpp(acc);
                 if ((tid & 63) == 63) scratch[tid >> 6] = wsum;
@@ -512,15 +513,15 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
     a.Xt = gp->Xt; a.alpha = gp->alpha; a.chain = chain; a.chain_logp = chain_logp;
     a.n_accept = reinterpret_cast<unsigned long long*>(n_accept); a.run_state = e->run_state;
     a.K = K; a.W = e->W; a.n0 = n0; a.d = e->d; a.Npad = gp->Npad; a.thin_by = thin_by; a.spin_limit = 1 << 20;
-    a.amp = exp(gp->log_amp); a.mean = gp->mean;
+    a.amp = exp(gp->log_amp); a.mean = gp->mean; a.kf = gp->kf;
     const int db = dim_bucket(e->d);
     // lanes x pairs-per-lane must cover Npad/2 point pairs; the classic kernel's lane->point map (and therefore its
     // summation order) is reproduced exactly when T == e->threads.
     const int T = e->threads;
     const int ppt = (gp->Npad / 2 + T - 1) / T;
-    if (ppt == 1) { ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL((ens_stream_kernel<D, 1, 1024>), dim3(e->stream_grid, e->E), dim3(T), 0, s, a)); }
-    else if (ppt == 2 && T <= 512) { ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL((ens_stream_kernel<D, 2, 512>), dim3(e->stream_grid, e->E), dim3(T), 0, s, a)); }
-    else if (ppt <= 4 && T <= 512 && db <= 12) { ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL((ens_stream_kernel<D, 4, 512>), dim3(e->stream_grid, e->E), dim3(T), 0, s, a)); }
+    if (ppt == 1) { ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((ens_stream_kernel<D, 1, 1024, GENERIC>), dim3(e->stream_grid, e->E), dim3(T), 0, s, a))); }
+    else if (ppt == 2 && T <= 512) { ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((ens_stream_kernel<D, 2, 512, GENERIC>), dim3(e->stream_grid, e->E), dim3(T), 0, s, a))); }
+    else if (ppt <= 4 && T <= 512 && db <= 12) { ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((ens_stream_kernel<D, 4, 512, GENERIC>), dim3(e->stream_grid, e->E), dim3(T), 0, s, a))); }
     else return ALABI_BAD_ARGUMENT;
     hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp,
                        e->hist + (size_t)K * WT * row, WT, e->d, 0);
@@ -548,7 +549,7 @@ int launch_ens_half_args(alabi_ens* e, const HalfArgs& args, int nblocks, hipStr
     if (nblocks <= 0) return ALABI_OK;
     const int db = dim_bucket(e->d);
     const int threads = e->threads;
-    ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(ens_half_kernel<D>, dim3(nblocks, e->E), dim3(threads), 0, s, args));
+    ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(e->gp->kf.type, hipLaunchKernelGGL((ens_half_kernel<D, GENERIC>), dim3(nblocks, e->E), dim3(threads), 0, s, args)));
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }
@@ -557,7 +558,7 @@ int launch_ens_lnprob(alabi_ens* e, const double* coords, int nwalkers, double* 
     const int db = dim_bucket(e->d);
     alabi_gp* gp = e->gp;
     ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(ens_lnprob_kernel<D>, dim3(nwalkers), dim3(e->threads), 0, s, coords, e->d,
-                                              gp->Xt, gp->alpha, gp->Npad, exp(gp->log_amp), gp->mean, e->consts,
+                                              gp->Xt, gp->alpha, gp->Npad, exp(gp->log_amp), gp->mean, gp->kf, e->consts,
                                               logp));
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;

@@ -28,7 +28,7 @@ prepare_inputs_kernel(const double* __restrict__ X, int N, int Npad, int d, int 
 // One 64x64 tile of the lower triangle per workgroup; lanes run along a row (coalesced
 // 512-byte row segments), each thread owns 16 rows of one column.
 __global__ void __launch_bounds__(256)
-assemble_lower_kernel(const double* __restrict__ Xt, int N, int Npad, int d, double amp, double wn,
+assemble_lower_kernel(const double* __restrict__ Xt, int N, int Npad, int d, double amp, double wn, KernelFn kf,
                       double* __restrict__ K) {
     __shared__ double xi[ALABI_MAX_DIM][64];
     __shared__ double xj[ALABI_MAX_DIM][64];
@@ -54,7 +54,7 @@ assemble_lower_kernel(const double* __restrict__ Xt, int N, int Npad, int d, dou
             double df = xi[k][r] - xj[k][c];
             r2 = fma(df, df, r2);
         }
-        double v = amp * exp(-0.5 * r2);
+        double v = amp * radial(r2, kf);
         if (gr == gc) v += wn;
         if (gr >= N || gc >= N) v = (gr == gc) ? 1.0 : 0.0;
         K[(size_t)gr * Npad + gc] = v;
@@ -64,7 +64,7 @@ assemble_lower_kernel(const double* __restrict__ Xt, int N, int Npad, int d, dou
 // Rectangular kernel.get_value(x1, x2): both inputs raw [n,d] row-major.
 __global__ void __launch_bounds__(256)
 kernel_matrix_kernel(const double* __restrict__ X1, int n1, const double* __restrict__ X2, int n2,
-                     int d, double amp, DimVec inv_len, double* __restrict__ K) {
+                     int d, double amp, DimVec inv_len, KernelFn kf, double* __restrict__ K) {
     __shared__ double xi[ALABI_MAX_DIM][64];
     __shared__ double xj[ALABI_MAX_DIM][64];
     int bi = blockIdx.y, bj = blockIdx.x;
@@ -87,7 +87,7 @@ kernel_matrix_kernel(const double* __restrict__ X1, int n1, const double* __rest
             double df = xi[k][r] - xj[k][c];
             r2 = fma(df, df, r2);
         }
-        K[(size_t)gr * n2 + gc] = amp * exp(-0.5 * r2);
+        K[(size_t)gr * n2 + gc] = amp * radial(r2, kf);
     }
 }
 
@@ -103,15 +103,15 @@ int launch_assemble(alabi_gp* gp, hipStream_t s) {
     int nb = gp->Npad / 64;
     int tiles = nb * (nb + 1) / 2;
     hipLaunchKernelGGL(assemble_lower_kernel, dim3(tiles), dim3(256), 0, s, gp->Xt, gp->N, gp->Npad,
-                       gp->d, exp(gp->log_amp), exp(gp->log_wn), gp->L);
+                       gp->d, exp(gp->log_amp), exp(gp->log_wn), gp->kf, gp->L);
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }
 
 int launch_kernel_matrix(const double* X1, int n1, const double* X2, int n2, int d, double amp,
-                         const DimVec& inv_len, double* K, hipStream_t s) {
+                         const DimVec& inv_len, KernelFn kf, double* K, hipStream_t s) {
     dim3 grid((n2 + 63) / 64, (n1 + 63) / 64);
-    hipLaunchKernelGGL(kernel_matrix_kernel, grid, dim3(256), 0, s, X1, n1, X2, n2, d, amp, inv_len, K);
+    hipLaunchKernelGGL(kernel_matrix_kernel, grid, dim3(256), 0, s, X1, n1, X2, n2, d, amp, inv_len, kf, K);
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

@@ -33,6 +33,20 @@ __host__ __device__ inline int dim_bucket(int d) {
         default: return ALABI_BAD_ARGUMENT;                           \
     }
 
+// GENERIC = false compiles the squared-exponential alone (no run-time switch in the hot loops).
+template <bool GENERIC = true>
+__device__ inline double radial(double r2, KernelFn kf) {
+    if (!GENERIC || kf.type == 0) return exp(-0.5 * r2);
+    if (kf.type == 1) { const double r = sqrt(3.0 * r2); return (1.0 + r) * exp(-r); }
+    if (kf.type == 2) { const double r = sqrt(5.0 * r2); return (1.0 + r + r * r / 3.0) * exp(-r); }
+    return exp(-kf.alpha * log1p(0.5 * r2 / kf.alpha));
+}
+
+// Run `...` with `constexpr bool GENERIC` = (kernel family != squared exponential).
+#define ALABI_DISPATCH_KERNEL(KTYPE, ...)                         \
+    if ((KTYPE) == 0) { constexpr bool GENERIC = false; __VA_ARGS__; } \
+    else { constexpr bool GENERIC = true; __VA_ARGS__; }
+
 // Sum over the 64 lanes of a wavefront (result valid in every lane).
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -84,9 +98,9 @@ __device__ inline double block_sum(double v, double* scratch) {
 // sum_n alpha[n] * exp(-0.5 * |Xt[:,n] - q|^2) over all (padded) training points, one
 // query per workgroup: lanes run along n (coalesced SoA loads), then a block reduction.
 // q holds the query already multiplied by inv_len; padded points carry alpha = 0.
-template <int D>
+template <int D, bool GENERIC = true>
 __device__ inline double gp_kernel_dot_block(const double* __restrict__ Xt, const double* __restrict__ alpha,
-                                             int Npad, const double* q_lds, double* scratch) {
+                                             int Npad, const double* q_lds, double* scratch, KernelFn kf) {
     double q[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) q[k] = q_lds[k];
@@ -98,7 +112,7 @@ __device__ inline double gp_kernel_dot_block(const double* __restrict__ Xt, cons
             double df = Xt[(size_t)k * Npad + n] - q[k];
             r2 = fma(df, df, r2);
         }
-        acc = fma(alpha[n], exp(-0.5 * r2), acc);
+        acc = fma(alpha[n], radial<GENERIC>(r2, kf), acc);
     }
     return block_sum(acc, scratch);
 }

@@ -30,21 +30,21 @@ template <int D>
 __global__ void __launch_bounds__(256)
 predict_mean_rowwise_kernel(const double* __restrict__ Xt, const double* __restrict__ alpha, int Npad,
                             const double* __restrict__ Xs, int d, DimVec inv_len, double amp, double mean,
-                            double* __restrict__ mu) {
+                            KernelFn kf, double* __restrict__ mu) {
     __shared__ double q[ALABI_MAX_DIM];
     __shared__ double scratch[16];
     const long long m = blockIdx.x;
     if (threadIdx.x < D) q[threadIdx.x] = (threadIdx.x < d) ? Xs[m * d + threadIdx.x] * inv_len.v[threadIdx.x] : 0.0;
     __syncthreads();
-    double s = gp_kernel_dot_block<D>(Xt, alpha, Npad, q, scratch);
+    double s = gp_kernel_dot_block<D>(Xt, alpha, Npad, q, scratch, kf);
     if (threadIdx.x == 0) mu[m] = fma(amp, s, mean);
 }
 
-template <int D>
+template <int D, bool GENERIC>
 __global__ void __launch_bounds__(256)
 predict_mean_tile_kernel(const double* __restrict__ Xt, const double* __restrict__ alpha, int Npad,
                          const double* __restrict__ Xs, int d, long long M, DimVec inv_len, double amp,
-                         double mean, double* __restrict__ mu) {
+                         double mean, KernelFn kf, double* __restrict__ mu) {
     __shared__ double xt[D][256];
     __shared__ double al[256];
     __shared__ double part[4][64];
@@ -70,7 +70,7 @@ predict_mean_tile_kernel(const double* __restrict__ Xt, const double* __restrict
                 double df = xt[k][nn] - q[k];
                 r2 = fma(df, df, r2);
             }
-            acc = fma(al[nn], exp(-0.5 * r2), acc);
+            acc = fma(al[nn], radial<GENERIC>(r2, kf), acc);
         }
     }
     part[w][c] = acc;
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256, 2)
 predict_var_kernel(const double* __restrict__ L, const double* __restrict__ dinv, const double* __restrict__ Xt,
                    const double* __restrict__ alpha, int N, int Npad, const double* __restrict__ Xs, int d, long long M, DimVec inv_len,
                    double amp, double mean, double* __restrict__ ws, double* __restrict__ mu,
-                   double* __restrict__ var, int split) {
+                   double* __restrict__ var, int split, KernelFn kf) {
     // `split` is always 0.  The `split != k` tests below are opaque to the compiler and put the GEMM step and the
     // unrolled diagonal solve into basic blocks of their own: as ONE block the register allocator hoists the
     // solve's LDS reads into the GEMM phase and spills 100 VGPRs to scratch inside the hot loop
@@ -132,7 +132,7 @@ predict_var_kernel(const double* __restrict__ L, const double* __restrict__ dinv
                     double df = xtr[k][r] - q[k];
                     r2 = fma(df, df, r2);
                 }
-                double kv = (kb * 64 + r < N) ? amp * exp(-0.5 * r2) : 0.0;
+                double kv = (kb * 64 + r < N) ? amp * radial(r2, kf) : 0.0;
                 mu_acc = fma(kv, alb[r], mu_acc);
                 Vs[r][c] = kv;
             }
@@ -230,13 +230,13 @@ int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu,
     if (M <= 4096) {
         ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(predict_mean_rowwise_kernel<D>, dim3((unsigned)M), dim3(256), 0, s,
                                                   gp->Xt, gp->alpha, gp->Npad, Xs, gp->d, gp->inv_len, amp,
-                                                  gp->mean, mu));
+                                                  gp->mean, gp->kf, mu));
     } else {
         const long long tiles = (M + 63) / 64;
         if (tiles > 0x7fffffffLL) return ALABI_BAD_ARGUMENT;
-        ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(predict_mean_tile_kernel<D>, dim3((unsigned)tiles), dim3(256), 0, s,
+        ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_mean_tile_kernel<D, GENERIC>), dim3((unsigned)tiles), dim3(256), 0, s,
                                                   gp->Xt, gp->alpha, gp->Npad, Xs, gp->d, M, gp->inv_len, amp,
-                                                  gp->mean, mu));
+                                                  gp->mean, gp->kf, mu)));
     }
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
@@ -260,7 +260,7 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
     const double amp = exp(gp->log_amp);
     ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(predict_var_kernel<D>, dim3(grid), dim3(256), 0, s, gp->L, gp->dinv, gp->Xt,
                                               gp->alpha, gp->N, gp->Npad, Xs, gp->d, M, gp->inv_len, amp,
-                                              gp->mean, gp->ws, mu, var, 0));
+                                              gp->mean, gp->ws, mu, var, 0, gp->kf));
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

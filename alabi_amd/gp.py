@@ -52,10 +52,12 @@ class _KernelView:
         return self._gp.ndim
 
     def get_parameter_names(self, include_frozen=False):
-        return tuple(["k1:log_constant"] + [f"k2:metric:log_M_{i}_{i}" for i in range(self._gp.ndim)])
+        extra = ["k2:log_alpha"] if self._gp.kernel_name == "RationalQuadraticKernel" else []
+        return tuple(["k1:log_constant"] + extra + [f"k2:metric:log_M_{i}_{i}" for i in range(self._gp.ndim)])
 
     def get_parameter_vector(self, include_frozen=False):
-        return np.concatenate([[self._gp.log_constant], self._gp.log_M])
+        extra = [self._gp.log_alpha] if self._gp.kernel_name == "RationalQuadraticKernel" else []
+        return np.concatenate([[self._gp.log_constant], extra, self._gp.log_M])
 
     def get_value(self, x1, x2=None, diag=False):
         gp = self._gp
@@ -65,6 +67,7 @@ class _KernelView:
         b = a if x2 is None else _to_dev(x2, 2)
         out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=a.device)
         st = _lib.lib().alabi_kernel_matrix(_lib.ptr(a), a.shape[0], _lib.ptr(b), b.shape[0], gp.ndim,
+                                            _lib.KERNEL_CODES[gp.kernel_name], float(gp.log_alpha),
                                             float(gp.log_constant), _lib.host_doubles(gp.log_M), _lib.ptr(out),
                                             _lib.current_stream())
         _lib.check(st, "alabi_kernel_matrix")
@@ -99,7 +102,11 @@ class _SolverView:
 
 class HipGP:
     def __init__(self, ndim, mean=0.0, white_noise=-12.0, log_constant=0.0, log_M=None,
-                 fit_mean=True, fit_white_noise=True):
+                 fit_mean=True, fit_white_noise=True, kernel="ExpSquaredKernel", log_alpha=1.0):
+        if kernel not in _lib.KERNEL_CODES:
+            raise ValueError(f"Kernel '{kernel}' is not a valid option. Valid options: {', '.join(_lib.KERNEL_CODES)}")
+        self.kernel_name = kernel
+        self.log_alpha = float(log_alpha)      # RationalQuadraticKernel only (reference: log_alpha=1, core.py:1003)
         self.ndim = int(ndim)
         if not (1 <= self.ndim <= _lib.MAX_DIM):
             raise ValueError(f"ndim must be in [1, {_lib.MAX_DIM}]")
@@ -182,6 +189,8 @@ class HipGP:
         if self.fit_white_noise or include_frozen:
             names.append("white_noise:value")
         names.append("kernel:k1:log_constant")
+        if self.kernel_name == "RationalQuadraticKernel":
+            names.append("kernel:k2:log_alpha")
         names += [f"kernel:k2:metric:log_M_{i}_{i}" for i in range(self.ndim)]
         return tuple(names)
 
@@ -192,6 +201,8 @@ class HipGP:
         if self.fit_white_noise or include_frozen:
             v.append(self.white_noise_value)
         v.append(self.log_constant)
+        if self.kernel_name == "RationalQuadraticKernel":
+            v.append(self.log_alpha)
         v.extend(self.log_M.tolist())
         return np.array(v, dtype=np.float64)
 
@@ -209,6 +220,8 @@ class HipGP:
         if self.fit_white_noise or include_frozen:
             self.white_noise_value = float(p[i]); i += 1
         self.log_constant = float(p[i]); i += 1
+        if self.kernel_name == "RationalQuadraticKernel":
+            self.log_alpha = float(p[i]); i += 1
         self.log_M = p[i:i + self.ndim].copy()
         self.dirty = True
         self._y_set = False
@@ -219,6 +232,8 @@ class HipGP:
 
     # ------------------------------------------------------------------ compute / predict
     def _push_hyper(self):
+        _lib.check(_lib.lib().alabi_gp_set_kernel(self._handle, _lib.KERNEL_CODES[self.kernel_name], self.log_alpha),
+                   "alabi_gp_set_kernel")
         st = _lib.lib().alabi_gp_set_hyper(self._handle, self.mean_value, self.white_noise_value, self.log_constant,
                                            _lib.host_doubles(self.log_M))
         _lib.check(st, "alabi_gp_set_hyper")

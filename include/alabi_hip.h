@@ -55,6 +55,9 @@ int alabi_gp_destroy(alabi_gp* gp);
  * all three log_* values are natural logs (george convention). */
 int alabi_gp_set_hyper(alabi_gp* gp, double mean, double log_white_noise, double log_amp,
                        const double* log_M);
+/* Kernel family: 0 ExpSquaredKernel (default), 1 Matern32Kernel, 2 Matern52Kernel, 3 RationalQuadraticKernel
+ * (log_alpha used by 3 only) -- the four choices of init_gp(kernel=), alabi/core.py:1000-1014. */
+int alabi_gp_set_kernel(alabi_gp* gp, int kernel_type, double log_alpha);
 
 /* gp.compute(X) -- alabi/core.py:1158, :1430, :1577; gp_utils.py:243.  Assembles
  * K = k(X,X) + exp(log_white_noise) I and factorises it (lower Cholesky).  X is [N,d]
@@ -86,8 +89,8 @@ int alabi_gp_n(alabi_gp* gp, int* n /* host */);
 /* kernel.get_value(x1, x2) -- alabi/utility.py:549, :607.  K_out is [n1,n2] row-major,
  * no white noise. */
 int alabi_kernel_matrix(const double* X1, int n1, const double* X2, int n2, int d,
-                        double log_amp, const double* log_M /* host [d] */, double* K_out,
-                        void* stream);
+                        int kernel_type, double log_alpha, double log_amp,
+                        const double* log_M /* host [d] */, double* K_out, void* stream);
 
 /* Acquisition scan: utility.bape_utility / agp_utility / jones_utility evaluated on M
  * candidates + the arg-min that utility.minimize_objective takes over restarts --

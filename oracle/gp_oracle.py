@@ -20,11 +20,35 @@ from __future__ import annotations
 import numpy as np
 from scipy.linalg import cho_solve, cholesky, solve_triangular
 
-__all__ = ["sqexp_kernel", "OracleGP", "NotPositiveDefinite"]
+__all__ = ["sqexp_kernel", "stationary_kernel", "OracleGP", "NotPositiveDefinite"]
 
 
 class NotPositiveDefinite(np.linalg.LinAlgError):
     pass
+
+
+def stationary_kernel(x1, x2, log_amp, log_M, kernel="ExpSquaredKernel", log_alpha=1.0):
+    """amp * f(r2) for the four kernels init_gp offers (alabi/core.py:1000-1014), george definitions:
+    ExpSquared exp(-r2/2); Matern32 (1+s)exp(-s), s=sqrt(3 r2); Matern52 (1+s+s^2/3)exp(-s), s=sqrt(5 r2);
+    RationalQuadratic (1 + r2/(2 alpha))^-alpha."""
+    x1 = np.atleast_2d(np.asarray(x1, dtype=np.float64))
+    x2 = np.atleast_2d(np.asarray(x2, dtype=np.float64))
+    inv_m = np.exp(-np.asarray(log_M, dtype=np.float64))
+    r2 = np.zeros((x1.shape[0], x2.shape[0]))
+    for k in range(x1.shape[1]):
+        diff = x1[:, k][:, None] - x2[:, k][None, :]
+        r2 += diff * diff * inv_m[k]
+    if kernel == "ExpSquaredKernel":
+        f = np.exp(-0.5 * r2)
+    elif kernel == "Matern32Kernel":
+        s = np.sqrt(3.0 * r2); f = (1.0 + s) * np.exp(-s)
+    elif kernel == "Matern52Kernel":
+        s = np.sqrt(5.0 * r2); f = (1.0 + s + s * s / 3.0) * np.exp(-s)
+    elif kernel == "RationalQuadraticKernel":
+        a = np.exp(log_alpha); f = (1.0 + 0.5 * r2 / a) ** (-a)
+    else:
+        raise ValueError(kernel)
+    return np.exp(log_amp) * f
 
 
 def sqexp_kernel(x1, x2, log_amp, log_M):
@@ -47,7 +71,9 @@ class OracleGP:
     """Restatement of the george.GP protocol alabi uses (SURVEY.md section 8b seam #1)."""
 
     def __init__(self, ndim, mean=0.0, log_white_noise=-12.0, log_amp=0.0, log_M=None,
-                 fit_mean=True, fit_white_noise=True):
+                 fit_mean=True, fit_white_noise=True, kernel="ExpSquaredKernel", log_alpha=1.0):
+        self.kernel_name = kernel
+        self.log_alpha = float(log_alpha)
         self.ndim = int(ndim)
         self.mean = float(mean)
         self.log_white_noise = float(log_white_noise)
@@ -68,6 +94,8 @@ class OracleGP:
         if self.fit_white_noise or include_frozen:
             names.append("white_noise:value")
         names.append("kernel:k1:log_constant")
+        if self.kernel_name == "RationalQuadraticKernel":
+            names.append("kernel:k2:log_alpha")
         names += [f"kernel:k2:metric:log_M_{i}_{i}" for i in range(self.ndim)]
         return tuple(names)
 
@@ -78,6 +106,8 @@ class OracleGP:
         if self.fit_white_noise or include_frozen:
             v.append(self.log_white_noise)
         v.append(self.log_amp)
+        if self.kernel_name == "RationalQuadraticKernel":
+            v.append(self.log_alpha)
         v += list(self.log_M)
         return np.array(v, dtype=np.float64)
 
@@ -89,15 +119,20 @@ class OracleGP:
         if self.fit_white_noise or include_frozen:
             self.log_white_noise = float(p[i]); i += 1
         self.log_amp = float(p[i]); i += 1
+        if self.kernel_name == "RationalQuadraticKernel":
+            self.log_alpha = float(p[i]); i += 1
         self.log_M = p[i:i + self.ndim].copy()
         if self.log_M.size != self.ndim:
             raise ValueError("parameter vector has the wrong length")
         self._alpha = None
 
+    def _k(self, a, b):
+        return stationary_kernel(a, b, self.log_amp, self.log_M, self.kernel_name, self.log_alpha)
+
     # ---- compute / predict (george BasicSolver semantics) ---------------------------
     def get_matrix(self, x):
         """K = k(X,X) + exp(white_noise) * I  (reference call site: core.py:1158)."""
-        K = sqexp_kernel(x, x, self.log_amp, self.log_M)
+        K = self._k(x, x)
         K[np.diag_indices_from(K)] += np.exp(self.log_white_noise)
         return K
 
@@ -134,7 +169,7 @@ class OracleGP:
         """
         alpha = self._compute_alpha(y)
         xs = np.atleast_2d(np.asarray(t, dtype=np.float64))
-        Kxs = sqexp_kernel(xs, self._x, self.log_amp, self.log_M)
+        Kxs = self._k(xs, self._x)
         mu = Kxs @ alpha + self.mean
         if not (return_var or return_cov):
             return mu
@@ -143,7 +178,7 @@ class OracleGP:
             var = np.full(xs.shape[0], np.exp(self.log_amp))
             var -= np.sum(Kxs.T * KinvKxs, axis=0)
             return mu, var
-        cov = sqexp_kernel(xs, xs, self.log_amp, self.log_M) - Kxs @ KinvKxs
+        cov = self._k(xs, xs) - Kxs @ KinvKxs
         return mu, cov
 
     def predict_var_halfsolve(self, y, t):
@@ -154,7 +189,7 @@ class OracleGP:
         """
         alpha = self._compute_alpha(y)
         xs = np.atleast_2d(np.asarray(t, dtype=np.float64))
-        Kxs = sqexp_kernel(xs, self._x, self.log_amp, self.log_M)
+        Kxs = self._k(xs, self._x)
         V = solve_triangular(self._L, Kxs.T, lower=True, check_finite=False)
         return Kxs @ alpha + self.mean, np.exp(self.log_amp) - np.sum(V * V, axis=0)
 
