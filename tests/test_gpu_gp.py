@@ -205,3 +205,42 @@ def test_utility_scan_argmin(torch_gpu, algo):
     both = fin & np.isfinite(u_o)
     assert both.sum() > 0.5 * len(cand)
     assert abs(u_dev[idx] - np.min(u_o[both])) < 1e-5 * (1 + abs(u_dev[idx]))
+
+
+def test_full_size_configs_properties(torch_gpu):
+    """BASELINE.json's largest sizes through size-independent properties (the oracle is only run on a slice)."""
+    from alabi_amd import HipGP
+    from alabi_amd.utility import utility_scan
+    from alabi_amd.workloads import make_config
+    from oracle.gp_oracle import OracleGP
+    # C4: N=5000, d=10 -- oracle on 200 query points
+    cfg = make_config("C4"); h = cfg["hyper"]
+    g = HipGP(10, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(cfg["X"])
+    o = OracleGP(10, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(cfg["X"])
+    Xs = np.random.RandomState(0).uniform(-3, 3, (200, 10))
+    mu, var = g.predict(cfg["y"], Xs, return_var=True)
+    mu_o, var_o = o.predict(cfg["y"], Xs, return_var=True)
+    amp = np.exp(h["log_amp"])
+    assert np.max(np.abs(mu - mu_o) / (np.abs(mu_o) + 1)) <= 1e-8 and np.max(np.abs(var - var_o)) <= 1e-6 * amp
+    del g, o
+    # C5: N=10000, d=20 ARD -- properties only
+    cfg = make_config("C5"); h = cfg["hyper"]; X, y = cfg["X"], cfg["y"]; amp = np.exp(h["log_amp"])
+    g = HipGP(20, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+    idx = np.random.RandomState(1).choice(len(X), 500, replace=False)
+    mu, var = g.predict(y, X[idx], return_var=True)
+    assert np.max(np.abs(mu - y[idx])) < 1e-3 * (1 + np.max(np.abs(y)))          # interpolates its training data
+    assert np.all(np.abs(var) < 1e-3 * amp)                                        # variance collapses there
+    far = np.full((4, 20), 300.0)
+    mu_f, var_f = g.predict(y, far, return_var=True)
+    assert np.allclose(mu_f, h["mean"], atol=1e-9) and np.allclose(var_f, amp, rtol=1e-13)   # prior far away
+    Xq = np.random.RandomState(2).uniform(-3, 3, (4096 + 64, 20))
+    m1 = g.predict(y, Xq, return_cov=False); m2, v2 = g.predict(y, Xq, return_var=True)
+    assert np.max(np.abs(m1 - m2)) <= 1e-9 * (1 + np.max(np.abs(m1)))             # tile-mean == variance-path mean
+    assert np.all(v2 <= amp * (1 + 1e-12)) and np.all(v2 > -1e-6 * amp)            # 0 <= var <= amp up to rounding
+    m3, v3 = g.predict(y, Xq, return_var=True)
+    assert np.array_equal(m2, m3) and np.array_equal(v2, v3)                       # deterministic
+    best, val, i = utility_scan(g, y, Xq, cfg["bounds"], "bape")
+    u_i = -((2 * m2[i] + v2[i]) + (v2[i] + np.log(1 - np.exp(-v2[i]))))
+    assert i >= 0 and abs(val - u_i) <= 1e-9 * abs(u_i)
+    L = g.solver.get_factor()
+    assert float(L.diagonal().min()) > 0 and abs(g.solver.log_determinant - 2 * float(L.diagonal().log().sum())) < 1e-6
