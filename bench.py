@@ -27,37 +27,96 @@ if ROOT not in sys.path:
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = fp64 matrix peak (spec); MI355X_MICROARCH.md lists no fp64 row
 
 
-def cpu_baseline(cfg, budget_s=12.0):
-    """Reference-shaped CPU path (BASELINE.md B-ref): emcee's red-blue stretch move calling lnprob once per
-    walker per half step, each call = box prior + single-point mean-only GP predict with the factorisation
-    cached (the reference's CachedSurrogateLikelihood route, alabi/core.py:53-122, :2073-2100).  1 core."""
-    from oracle.gp_oracle import OracleGP, sqexp_kernel
-    from oracle import stretch_oracle as so
-    from oracle.utility_oracle import lnprior_uniform
+_CPU = {}   # worker-side state of the CPU baseline (inherited by fork: no pickling of the GP)
+
+
+def _cpu_setup(cfg):
+    from oracle.gp_oracle import OracleGP
     h = cfg["hyper"]
     gp = OracleGP(cfg["d"], h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(cfg["X"])
-    alpha = gp._compute_alpha(cfg["y"])
-    X, bounds = cfg["X"], cfg["bounds"]
+    _CPU.update(alpha=gp._compute_alpha(cfg["y"]), X=cfg["X"], bounds=cfg["bounds"], h=h)
 
-    def lnprob(theta):
-        lp = lnprior_uniform(theta, bounds)
-        if not np.isfinite(lp):
-            return -np.inf
-        k = sqexp_kernel(theta.reshape(1, -1), X, h["log_amp"], h["log_M"])
-        return float(k @ alpha + h["mean"]) + lp
 
+def _cpu_lnprob(theta):
+    """alabi's lnprob (core.py:2073-2100): uniform box prior + single-point mean-only predict, factorisation cached."""
+    from oracle.gp_oracle import sqexp_kernel
+    from oracle.utility_oracle import lnprior_uniform
+    lp = lnprior_uniform(theta, _CPU["bounds"])
+    if not np.isfinite(lp):
+        return -np.inf
+    h = _CPU["h"]
+    k = sqexp_kernel(theta.reshape(1, -1), _CPU["X"], h["log_amp"], h["log_M"])
+    return float((k @ _CPU["alpha"])[0] + h["mean"]) + lp
+
+
+def cpu_baseline_vectorized(cfg, budget_s=5.0):
+    """A stronger CPU statement than the reference's own call shape: the whole half-ensemble's proposals evaluated in one
+    NumPy call (what emcee's vectorize=True would allow).  Reported beside the reference-shaped baselines so the GPU/CPU
+    ratio is not read off the per-walker Python-call overhead alone."""
+    from oracle import stretch_oracle as so
+    from oracle.gp_oracle import sqexp_kernel
+    _cpu_setup(cfg)
+    h, alpha, X, bounds = _CPU["h"], _CPU["alpha"], _CPU["X"], _CPU["bounds"]
+
+    isd = np.exp(-0.5 * np.asarray(h["log_M"]))
+    Xs = X * isd; x2 = np.sum(Xs * Xs, axis=1); amp = np.exp(h["log_amp"])
+
+    def lnprob_batch(q):                      # r2 through one GEMM (BLAS, all threads), one exp pass, one GEMV
+        lp = so.box_lnprior_batch(q, bounds)
+        out = np.full(len(q), -np.inf)
+        ok = np.isfinite(lp)
+        if ok.any():
+            qs = q[ok] * isd
+            r2 = np.maximum(np.sum(qs * qs, axis=1)[:, None] + x2[None, :] - 2.0 * (qs @ Xs.T), 0.0)
+            out[ok] = amp * (np.exp(-0.5 * r2) @ alpha) + h["mean"]
+        return out
+
+    W = cfg["W"]
+    assert np.allclose(lnprob_batch(cfg["p0"][:8]), sqexp_kernel(cfg["p0"][:8], X, h["log_amp"], h["log_M"]) @ alpha + h["mean"],
+                       rtol=1e-6, atol=1e-6)
+    coords = cfg["p0"].copy(); logp = lnprob_batch(coords)
+    rs = np.random.RandomState(7); ids = np.arange(W)
+    t0 = time.perf_counter(); nsteps = 0
+    while time.perf_counter() - t0 < budget_s:
+        lab = ids % 2; rs.shuffle(lab)
+        order = np.concatenate([ids[lab == 0], ids[lab == 1]]); n0 = W - int(lab.sum())
+        partner = np.where(lab == 0, rs.randint(W - n0, size=W), rs.randint(max(n0, 1), size=W))
+        coords, logp, _ = so.stretch_step_arrays(coords, logp, order, n0, rs.rand(W), partner, rs.rand(W), lnprob_batch)
+        nsteps += 1
+    dt = time.perf_counter() - t0
+    return {"value": cfg["W"] * nsteps / dt, "unit": "samples/s", "cores": "numpy default threads", "kind": "port",
+            "sample": f"{nsteps} stretch-move steps x {cfg['W']} walkers ({dt:.1f} s), half-ensemble proposals evaluated "
+                      "in one NumPy call (not the reference's call shape)"}
+
+
+def cpu_baseline(cfg, budget_s=10.0, cores=1):
+    """Reference-shaped CPU path (BASELINE.md B-ref): emcee's red-blue stretch move calling lnprob once per walker per
+    half step (CachedSurrogateLikelihood route, alabi/core.py:53-122).  cores > 1 hands the per-walker calls to a
+    process pool with pool.map, as run_emcee(multi_proc=True) does (core.py:2300, :2322).  Must run BEFORE this process
+    touches the GPU (the pool forks)."""
+    from oracle import stretch_oracle as so
+    _cpu_setup(cfg)
+    pool = None
+    map_fn = map
+    if cores > 1:
+        import multiprocessing as mp
+        pool = mp.get_context("fork").Pool(cores)
+        map_fn = pool.map
     coords = cfg["p0"].copy()
-    logp = np.array([lnprob(c) for c in coords])
+    logp = np.array(list(map_fn(_cpu_lnprob, list(coords))))
     rs = np.random.RandomState(12345)
     t0 = time.perf_counter()
     nsteps = 0
     while time.perf_counter() - t0 < budget_s:
-        coords, logp, _ = so.emcee_literal_step(coords, logp, lnprob, rs)
+        coords, logp, _ = so.emcee_literal_step(coords, logp, _cpu_lnprob, rs, map_fn=map_fn)
         nsteps += 1
     dt = time.perf_counter() - t0
-    return {"value": cfg["W"] * nsteps / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+    if pool is not None:
+        pool.close(); pool.join()
+    return {"value": cfg["W"] * nsteps / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{nsteps} stretch-move steps x {cfg['W']} walkers ({dt:.1f} s), one Python lnprob call per "
-                      "walker per half step, single-point mean-only predict with cached factorisation"}
+                      "walker per half step" + (" mapped over a process pool" if cores > 1 else "") +
+                      ", single-point mean-only predict with cached factorisation"}
 
 
 def main():
@@ -87,6 +146,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # CPU baselines first: the multi-core one forks a pool, which must happen before the GPU is initialised
+    cpu_base = cpu_base_all = cpu_base_vec = None
+    if world == 1 and not args.no_cpu_baseline:
+        cfg0 = make_config(args.config, N=args.ntrain, W=args.walkers)
+        cpu_base = cpu_baseline(cfg0, budget_s=10.0, cores=1)
+        cpu_base_vec = cpu_baseline_vectorized(cfg0, budget_s=5.0)
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncores = max(1, min(ncores, 64))
+        if ncores > 1:
+            try:
+                cpu_base_all = cpu_baseline(cfg0, budget_s=8.0, cores=ncores)
+            except Exception as ex:  # noqa: BLE001
+                cpu_base_all = {"error": repr(ex)[:200], "cores": ncores}
     # ALABI_DIST_BACKEND=gloo is a TEST rig (several ranks on one GPU, which RCCL refuses); the driver's runs use nccl
     backend = os.environ.get("ALABI_DIST_BACKEND", "nccl")
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
@@ -257,12 +329,29 @@ def main():
                     gp.predict_device(y_dev, Xs, return_var=var)
                 torch.cuda.synchronize()
                 extras[label] = M * reps / (time.perf_counter() - t1)
+            # secondary rooflines (wall-clock around the call incl. launch overhead; kernel-only times are in profiles/).
+            # predict_var: per query point N^2 flops for the triangular solve L^-1 k* (N^2/2 fma) + N(2d+3) for k*.
+            pv_flops = 65536.0 * (N * N + N * (2 * d + 3))
+            pv_tf = pv_flops * extras["predict_meanvar_pts_per_s_M65536"] / 65536.0 / 1e12
+            extras["roofline_predict_var"] = {"bound": "mfma", "achieved": pv_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                              "frac": pv_tf / FP64_PEAK_TFLOPS, "kernel": f"predict_var_kernel<{d}>"}
+            ch_tf = extras["cholesky_gflops"] / 1e3
+            extras["roofline_cholesky"] = {"bound": "mfma", "achieved": ch_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": ch_tf / FP64_PEAK_TFLOPS, "kernel": "potrf_diag+trsm_panel+syrk_update (N^3/3 flops)",
+                                           "note": "N=2000 is latency-bound on the panel critical path; see DESIGN.md for N=10000"}
             out["extras"] = extras
         if shard_info is not None:
             out["sharded_ensemble"] = shard_info
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
-            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
+            out["speedup_vs_cpu_baseline"] = value / cpu_base["value"]
+            if cpu_base_vec is not None:
+                out["cpu_baseline_vectorized"] = cpu_base_vec
+                out["speedup_vs_cpu_baseline_vectorized"] = value / cpu_base_vec["value"]
+            if cpu_base_all is not None:
+                out["cpu_baseline_all_cores"] = cpu_base_all
+                if "value" in cpu_base_all:
+                    out["speedup_vs_cpu_baseline_all_cores"] = value / cpu_base_all["value"]
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -148,7 +148,7 @@ def stretch_step_arrays(coords, logp, order, n0, u_z, partner, u_acc, lnprob_bat
     return coords, logp, accepted
 
 
-def emcee_literal_step(coords, logp, lnprob_one, random, a=2.0, record=None):
+def emcee_literal_step(coords, logp, lnprob_one, random, a=2.0, record=None, map_fn=map):
     """emcee 3.x RedBlueMove.propose with StretchMove.get_proposal, draw for draw.
 
     ``lnprob_one(theta[d]) -> float`` is called once per walker, as emcee's
@@ -175,7 +175,7 @@ def emcee_literal_step(coords, logp, lnprob_one, random, a=2.0, record=None):
         factors = (ndim - 1.0) * np.log(zz)
         rint = random.randint(Nc, size=(Ns,))
         q = c[rint] - (c[rint] - s) * zz[:, None]
-        new_log_probs = np.array([float(lnprob_one(qq)) for qq in q])
+        new_log_probs = np.array([float(v) for v in map_fn(lnprob_one, list(q))])   # emcee: pool.map when a pool is given
         uacc = np.empty(Ns)
         for i, (j, f, nlp) in enumerate(zip(all_inds[S1], factors, new_log_probs)):
             lnpdiff = f + nlp - logp[j]
