@@ -91,6 +91,7 @@ struct DrawBuffers {
     int* partner;    // raw partner index into the complementary list (by list position)
     double* u_z;     // raw uniforms (by list position)
     double* u_acc;
+    unsigned long long* packed;   // 4 words per list position: walker | partner << 32, zz, lnfac, lnu (persistent kernel)
 };
 }  // namespace alabi
 

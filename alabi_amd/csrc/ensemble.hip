@@ -60,11 +60,17 @@ __device__ inline void write_record(const DrawBuffers& b, size_t pos, int wid, i
                                     double a, int d) {
     const double t1 = (a - 1.0) * u_z + 1.0;
     const double zz = (t1 * t1) / a;
+    const double lnfac = ((double)d - 1.0) * log(zz), lnu = log(u_acc);
     b.order[pos] = wid;
     b.cw[pos] = cw;
     b.zz[pos] = zz;
-    b.lnfac[pos] = ((double)d - 1.0) * log(zz);
-    b.lnu[pos] = log(u_acc);
+    b.lnfac[pos] = lnfac;
+    b.lnu[pos] = lnu;
+    unsigned long long* pk = b.packed + 4 * pos;   // the same record in one 32-byte line for the persistent kernel
+    pk[0] = (unsigned long long)(unsigned)wid | ((unsigned long long)(unsigned)cw << 32);
+    pk[1] = (unsigned long long)__double_as_longlong(zz);
+    pk[2] = (unsigned long long)__double_as_longlong(lnfac);
+    pk[3] = (unsigned long long)__double_as_longlong(lnu);
 }
 
 // grid = (steps of the chunk, ensembles); dynamic LDS = W * (8 + 4 + 4) bytes.
@@ -321,32 +327,69 @@ __device__ inline void st_sc1(unsigned long long* p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef ALABI_STREAM_PROF
+__device__ long long g_stream_prof[16];
+#endif
+
+// Sum of the wave partials s[0..15] (zeros beyond the last compute wave) in exactly the order wave_sum_dpp adds
+// lanes 0..15 of a row -- a balanced binary tree -- so this path and ens_half_kernel agree bit for bit.
+__device__ inline double wave_partials_tree(const double* s, int nw) {
+    const f64x2 a = reinterpret_cast<const f64x2*>(s)[0], b = reinterpret_cast<const f64x2*>(s)[1];
+    const f64x2 c = reinterpret_cast<const f64x2*>(s)[2], d = reinterpret_cast<const f64x2*>(s)[3];
+    const double lo8 = ((d.y + d.x) + (c.y + c.x)) + ((b.y + b.x) + (a.y + a.x));
+    if (nw <= 8) return lo8;
+    const f64x2 e = reinterpret_cast<const f64x2*>(s)[4], f = reinterpret_cast<const f64x2*>(s)[5];
+    const f64x2 g = reinterpret_cast<const f64x2*>(s)[6], h = reinterpret_cast<const f64x2*>(s)[7];
+    const double hi8 = ((h.y + h.x) + (g.y + g.x)) + ((f.y + f.x) + (e.y + e.x));
+    return hi8 + lo8;
+}
+
+// blockDim.x = 64 + compute threads (a multiple of 64) + 64, three roles:
+//   wave 0          the ONLY wave on the hand-off chain: polls the two rows, forms the proposal, publishes it in LDS,
+//                   and after the reduction does the accept test and the one row store.  It computes no kernel values
+//                   and issues no other memory operation: gfx950 returns a wave's vector memory operations in issue
+//                   order (one vmcnt), so any ordinary load or store would put its latency in front of the next poll.
+//   waves 1..nwc    the training-set share of each lane lives in VGPRs for the whole launch; between the two barriers
+//                   of a proposal they evaluate the kernel sum and leave one partial per wave in LDS.
+//   last wave       fetches the packed proposal records (one 32-byte load) three proposals ahead into an LDS ring.
+// The chain, the thinning and the acceptance counters are NOT written here: every version of every walker is a row of
+// `hist` (coords, logp, accepted), and ens_hist_chain_kernel copies it out after the launch at HBM speed.
 template <int D, int PPT, int TMAX, bool GENERIC>
 __global__ void __launch_bounds__(TMAX)
 ens_stream_kernel(StreamArgs p) {
-    __shared__ double qs_s[ALABI_MAX_DIM];
-    __shared__ double scratch[16];
-    __shared__ int ctl_s[2];   // [0] proposal in bounds, [1] abort
-    const int tid = threadIdx.x, T = blockDim.x;
+    __shared__ __attribute__((aligned(16))) double scratch[2][16];   // wave partials, by proposal parity
+    __shared__ unsigned long long rec_s[4][4];                       // proposal-record ring (last wave -> wave 0)
+    __shared__ __attribute__((aligned(16))) double qs_s[2][ALABI_MAX_DIM];   // scaled proposal, by proposal parity
+    __shared__ double consts_s[3][ALABI_MAX_DIM];                    // [0] 1/length scale, [1] lower bound, [2] upper bound
+    __shared__ int ctl_s[2][2];                                      // [parity][0] proposal inside the box; [0][1] abort
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int TC = blockDim.x - 128, nwc = TC >> 6;
+    const bool comm = wv == 0, service = wv == nwc + 1, compute = !comm && !service;
     const int b = blockIdx.x, e = blockIdx.y, E = gridDim.y;
-    const int WT = p.W * E, row = p.d + 1;
-    // training-set share of this lane, resident for the whole launch
-    const int half = p.Npad >> 1;
+    const int WT = p.W * E, row = p.d + 2;
+#ifdef ALABI_STREAM_PROF
+    long long prof[5] = {0, 0, 0, 0, 0};
+    const long long prof_begin = clock64();
+#endif
+    // training-set share of this lane, resident for the whole launch (same lane -> point map as ens_half_kernel)
+    const int half = p.Npad >> 1, ct = tid - 64;
     f64x2 xa[PPT][D], aa[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        const int idx = tid + j * T;
-        const bool v = idx < half;
+        const int idx = ct + j * TC;
+        const bool v = compute && idx < half;
 #pragma unroll
         for (int k = 0; k < D; ++k)
             xa[j][k] = v ? reinterpret_cast<const f64x2*>(p.Xt + (size_t)k * p.Npad)[idx] : f64x2{0.0, 0.0};
         aa[j] = v ? reinterpret_cast<const f64x2*>(p.alpha)[idx] : f64x2{0.0, 0.0};
     }
-    const double* inv_len = p.consts;
-    const double* lo = p.consts + ALABI_MAX_DIM;
-    const double* hi = p.consts + 2 * ALABI_MAX_DIM;
-    if (tid == 0) ctl_s[1] = 0;
-    __syncthreads();
+    if (tid < ALABI_MAX_DIM) {
+        consts_s[0][tid] = (tid < p.d) ? p.consts[tid] : 0.0;
+        consts_s[1][tid] = (tid < p.d) ? p.consts[ALABI_MAX_DIM + tid] : 0.0;
+        consts_s[2][tid] = (tid < p.d) ? p.consts[2 * ALABI_MAX_DIM + tid] : 0.0;
+    }
+    if (tid < 32) scratch[tid >> 4][tid & 15] = 0.0;
+    if (tid < 4) ctl_s[tid >> 1][tid & 1] = 0;
 
     // This workgroup's proposals: list positions b, b+G, b+2G, ... of every half step, in (step, split, position)
     // order.  Every dependency points to an EARLIER half step, so the globally oldest unfinished proposal can always
@@ -361,117 +404,157 @@ ens_stream_kernel(StreamArgs p) {
             if (split == 0) split = 1; else { split = 0; ++t; }
         }
     };
-    // proposal records are read one proposal ahead (they depend on nothing), so their latency is off the chain
-    int n_w = 0, n_cw = 0;
-    double n_zz = 0.0, n_lnfac = 0.0, n_lnu = 0.0;
-    auto fetch_record = [&](int t, int split, int bb) {
-        if (tid < 64 && t < p.K) {
-            const size_t pos = ((size_t)t * E + e) * p.W + (split ? p.n0 : 0) + bb;
-            n_w = p.rec.order[pos]; n_cw = p.rec.cw[pos];
-            n_zz = p.rec.zz[pos]; n_lnfac = p.rec.lnfac[pos]; n_lnu = p.rec.lnu[pos];
-        }
+    // Proposal records depend on nothing: the last wave fetches them three proposals ahead (lane l < 4 loads word l).
+    const unsigned long long* packed = p.rec.packed;
+    unsigned long long pend = 0;
+    int pt = 0, psplit = 0, pbb = b, pslot = 0;
+    auto record_load = [&](int t, int split, int bb) -> unsigned long long {
+        if (t >= p.K || lane >= 4) return 0ull;
+        const size_t pos = ((size_t)t * E + e) * p.W + (split ? p.n0 : 0) + bb;
+        return packed[4 * pos + lane];
     };
-    int t = 0, split = 0, bb = b;          // b < G <= n0: the first item is valid
-    fetch_record(t, split, bb);
-    while (t < p.K) {
-        {
-            int t2 = t, s2 = split, b2 = bb;
-            next_item(t2, s2, b2);
-            int w = 0;
-            double qv = 0.0, sv = 0.0, lnfac = 0.0, lnu = 0.0;   // lane k < d: coordinate k; lane d: logp
-            if (tid < 64) {                                           // wave 0 fetches the two rows it depends on
-                w = n_w;
-                const int cw = n_cw;
-                const double zz = n_zz;
-                lnfac = n_lnfac; lnu = n_lnu;
-                fetch_record(t2, s2, b2);
-                // own row at version t, partner row at version t (+1 when the partner's half went first)
-                const unsigned long long* hw = p.hist + ((size_t)t * WT + w) * row;
-                const unsigned long long* hc = p.hist + ((size_t)(t + split) * WT + cw) * row;
-                // The data IS the flag (Guideline 16 form R2): every word of a row is one aligned 8-byte sc1 store
-                // over a sentinel NaN that no coordinate or log-probability can equal; lane k polls its own words.
-                unsigned long long ws = ALABI_HIST_EMPTY, wc = ALABI_HIST_EMPTY;
-                int ok = 1, spins = 0;
-                const bool mine = tid <= p.d, needc = tid < p.d;
-                while (true) {
-                    if (mine && ws == ALABI_HIST_EMPTY) ws = ld_sc1(hw + tid);
-                    if (needc && wc == ALABI_HIST_EMPTY) wc = ld_sc1(hc + tid);
-                    const int ready = (!mine || ws != ALABI_HIST_EMPTY) && (!needc || wc != ALABI_HIST_EMPTY);
-                    if (__all(ready)) break;
-                    if (++spins > p.spin_limit ||
-                        ((spins & 63) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        ok = 0;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (!ok && tid == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int inb = 1;
-                if (ok && mine) {
-                    sv = __longlong_as_double((long long)ws);
-                    if (needc) {
-                        const double cv = __longlong_as_double((long long)wc);
-                        qv = cv - (cv - sv) * zz;
-                        inb = (qv > lo[tid]) && (qv < hi[tid]);
-                        qs_s[tid] = qv * inv_len[tid];
-                    }
-                }
-                if (tid >= p.d && tid < D) qs_s[tid] = 0.0;
-                const int all_in = __all(inb);
-                if (tid == 0) { ctl_s[0] = all_in; if (!ok) ctl_s[1] = 1; }
-            }
-            __syncthreads();
-            if (ctl_s[1]) return;                                     // timed out somewhere: leave (host falls back)
-            const int inb = ctl_s[0];
-            double lp_new = -INFINITY;
-            if (inb) {
-                double q[D];
-#pragma unroll
-                for (int k = 0; k < D; ++k) q[k] = qs_s[k];
-                double acc = 0.0;
-#pragma unroll
-                for (int j = 0; j < PPT; ++j) {
-                    double r2a = 0.0, r2b = 0.0;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        const double da = xa[j][k].x - q[k], db = xa[j][k].y - q[k];
-                        r2a = fma(da, da, r2a);
-                        r2b = fma(db, db, r2b);
-                    }
-                    // same operation order as ens_half_kernel's lane (first pair by multiply, the rest by fma)
-                    acc = (j == 0) ? aa[j].x * radial<GENERIC>(r2a, p.kf) : fma(aa[j].x, radial<GENERIC>(r2a, p.kf), acc);
-                    acc = fma(aa[j].y, radial<GENERIC>(r2b, p.kf), acc);
-                }
-                const double wsum = wave_sum_dpp(acc);
-                if ((tid & 63) == 63) scratch[tid >> 6] = wsum;
-            }
-            __syncthreads();                                          // also frees qs_s / ctl_s for the next proposal
-            if (tid < 64) {
-                if (inb) {
-                    const int nw = T >> 6;
-                    double part = (tid < nw) ? scratch[tid] : 0.0;
-                    part = wave_sum_dpp(part);
-                    lp_new = fma(p.amp, lane_bcast(part, 63), p.mean);
-                }
-                const double lp_old = lane_bcast(sv, p.d);            // lane d loaded logp
-                const int acc_flag = (lnfac + lp_new - lp_old > lnu) ? 1 : 0;
-                // new row of the walker: lanes k < d coordinates, lane d logp
-                double outv = (tid < p.d) ? (acc_flag ? qv : sv) : (acc_flag ? lp_new : lp_old);
-                if (tid <= p.d) {
-                    st_sc1(p.hist + ((size_t)(t + 1) * WT + w) * row + tid, (unsigned long long)__double_as_longlong(outv));
-                    const long long done = p.run_state[1] + t + 1;
-                    if (done % p.thin_by == 0) {
-                        const size_t slot = (size_t)(done / p.thin_by - 1);
-                        if (tid < p.d) { if (p.chain) __builtin_nontemporal_store(outv, &p.chain[(slot * WT + w) * p.d + tid]); }
-                        else if (p.chain_logp) __builtin_nontemporal_store(outv, &p.chain_logp[slot * WT + w]);
-                    }
-                }
-                if (tid == 0 && acc_flag && p.n_accept) atomicAdd(p.n_accept + w, 1ull);
-            }
-            t = t2; split = s2; bb = b2;
+    if (service) {                                    // prologue: items 0 and 1 into the ring, item 2 in flight
+        for (int i = 0; i < 2; ++i) {
+            const unsigned long long v = record_load(pt, psplit, pbb);
+            if (lane < 4) rec_s[pslot & 3][lane] = v;
+            next_item(pt, psplit, pbb); ++pslot;
         }
+        pend = record_load(pt, psplit, pbb);
     }
+    __syncthreads();
+    int t = 0, split = 0, bb = b, item = 0;           // b < G <= n0: the first item is valid
+    while (t < p.K) {
+        int t2 = t, s2 = split, b2 = bb;
+        next_item(t2, s2, b2);
+        const int par = item & 1;
+        int w = 0;
+        double qv = 0.0, sv = 0.0, lnfac = 0.0, lnu = 0.0;   // wave 0; lane k < d: coordinate k, lane d: logp
+#ifdef ALABI_STREAM_PROF
+        const long long c0 = clock64(); long long c1 = c0;
+#endif
+        if (comm) {
+            const unsigned long long* rs = rec_s[item & 3];
+            const unsigned long long ids = rs[0];
+            w = (int)(unsigned)(ids & 0xffffffffull);
+            const int cw = (int)(unsigned)(ids >> 32);
+            const double zz = __longlong_as_double((long long)rs[1]);
+            lnfac = __longlong_as_double((long long)rs[2]); lnu = __longlong_as_double((long long)rs[3]);
+            const double il_r = consts_s[0][lane], lo_r = consts_s[1][lane], hi_r = consts_s[2][lane];
+            // own row at version t, partner row at version t (+1 when the partner's half went first)
+            const unsigned long long* hw = p.hist + ((size_t)t * WT + w) * row;
+            const unsigned long long* hc = p.hist + ((size_t)(t + split) * WT + cw) * row;
+            // The data IS the flag (Guideline 16 form R2): every word of a row is one aligned 8-byte sc1 store
+            // over a sentinel NaN that no coordinate or log-probability can equal; lane k polls its own words.
+            unsigned long long ws = ALABI_HIST_EMPTY, wc = ALABI_HIST_EMPTY;
+            int ok = 1, spins = 0;
+            const bool mine = lane <= p.d, needc = lane < p.d;
+            while (true) {
+                if (mine && ws == ALABI_HIST_EMPTY) ws = ld_sc1(hw + lane);
+                if (needc && wc == ALABI_HIST_EMPTY) wc = ld_sc1(hc + lane);
+                const int ready = (!mine || ws != ALABI_HIST_EMPTY) && (!needc || wc != ALABI_HIST_EMPTY);
+                if (__all(ready)) break;
+                if (++spins > p.spin_limit ||
+                    ((spins & 63) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    ok = 0;
+                    break;
+                }
+            }
+#ifdef ALABI_STREAM_PROF
+            c1 = clock64();
+#endif
+            int inb = 1;
+            double qs = 0.0;
+            if (ok && mine) {
+                sv = __longlong_as_double((long long)ws);
+                if (needc) {
+                    const double cv = __longlong_as_double((long long)wc);
+                    qv = cv - (cv - sv) * zz;
+                    inb = (qv > lo_r) && (qv < hi_r);
+                    qs = qv * il_r;
+                }
+            }
+            const int all_in = ok ? __all(inb) : 0;
+            if (lane < D) qs_s[par][lane] = qs;
+            if (lane == 0) {
+                ctl_s[par][0] = all_in;
+                if (!ok) {                            // bounded spin ran out: every workgroup leaves, the host falls back
+                    ctl_s[0][1] = 1;
+                    __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __syncthreads();                              // barrier A: the proposal is in LDS
+#ifdef ALABI_STREAM_PROF
+        const long long c2 = clock64();
+#endif
+        const int all_in = ctl_s[par][0];
+        if (compute && all_in) {
+            double q[D];                              // wave-uniform: moved to SGPRs
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double qk = qs_s[par][k];
+                q[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(qk)),
+                                        __builtin_amdgcn_readfirstlane(__double2loint(qk)));
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                double r2a = 0.0, r2b = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const double da = xa[j][k].x - q[k], db = xa[j][k].y - q[k];
+                    r2a = fma(da, da, r2a);
+                    r2b = fma(db, db, r2b);
+                }
+                // same operation order as ens_half_kernel's lane (first pair by multiply, the rest by fma)
+                acc = (j == 0) ? aa[j].x * radial<GENERIC>(r2a, p.kf) : fma(aa[j].x, radial<GENERIC>(r2a, p.kf), acc);
+                acc = fma(aa[j].y, radial<GENERIC>(r2b, p.kf), acc);
+                if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // four points in flight at a time: enough independent
+                                                                       // chains to cover the fp64 latency, bounded temporaries
+            }
+            const double wsum = wave_sum_dpp(acc);
+            if (lane == 63) scratch[par][wv - 1] = wsum;
+        }
+        if (service) {                                // under the compute waves' kernel sum: ring slot item+2, issue item+3
+            if (lane < 4) rec_s[pslot & 3][lane] = pend;
+            next_item(pt, psplit, pbb); ++pslot;
+            pend = record_load(pt, psplit, pbb);
+        }
+        __syncthreads();                              // barrier B: the wave partials are in LDS
+#ifdef ALABI_STREAM_PROF
+        const long long c3 = clock64();
+#endif
+        if (ctl_s[0][1]) return;
+        if (comm) {
+            double lp_new = -INFINITY;
+            if (all_in) lp_new = fma(p.amp, wave_partials_tree(scratch[par], nwc), p.mean);
+            const double lp_old = lane_bcast(sv, p.d);                // lane d loaded logp
+            const int acc_flag = (lnfac + lp_new - lp_old > lnu) ? 1 : 0;
+            // new row of the walker: lanes k < d coordinates, lane d logp, lane d+1 the acceptance flag
+            const double outv = (lane < p.d) ? (acc_flag ? qv : sv) : (acc_flag ? lp_new : lp_old);
+            const unsigned long long outw = (lane <= p.d) ? (unsigned long long)__double_as_longlong(outv)
+                                                          : (unsigned long long)acc_flag;
+            if (lane <= p.d + 1) st_sc1(p.hist + ((size_t)(t + 1) * WT + w) * row + lane, outw);
+        }
+        t = t2; split = s2; bb = b2; ++item;
+#ifdef ALABI_STREAM_PROF
+        { const long long c4 = clock64();
+          prof[0] += c1 - c0; prof[1] += c2 - c1; prof[2] += c3 - c2; prof[3] += c4 - c3; prof[4] += 1; }
+#endif
+    }
+#ifdef ALABI_STREAM_PROF
+    if (tid == 0 && blockIdx.x == 3 && blockIdx.y == 0) {
+        for (int i = 0; i < 5; ++i) g_stream_prof[i] = prof[i];
+        g_stream_prof[5] = clock64() - prof_begin;
+    }
+#endif
 }
+
+#ifdef ALABI_STREAM_PROF
+extern "C" int alabi_debug_stream_prof(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stream_prof), sizeof(long long) * 16);
+}
+#endif
 
 // hist[0] <- (coords, logp); and back: (coords, logp) <- hist[K]
 __global__ void __launch_bounds__(256)
@@ -482,29 +565,77 @@ ens_hist_fill_kernel(unsigned long long* __restrict__ h, size_t n) {
 __global__ void __launch_bounds__(256)
 ens_hist_copy_kernel(double* __restrict__ coords, double* __restrict__ logp, unsigned long long* __restrict__ hist_row,
                      int WT, int d, int to_hist) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= WT * (d + 1)) return;
-    const int w = i / (d + 1), k = i % (d + 1);
+    const int i = blockIdx.x * 256 + threadIdx.x, row = d + 2;
+    if (i >= WT * row) return;
+    const int w = i / row, k = i % row;
+    if (k > d) { if (to_hist) hist_row[i] = 0ull; return; }           // acceptance flag of version 0: unused
     double* src = (k < d) ? coords + (size_t)w * d + k : logp + w;
     if (to_hist) hist_row[i] = (unsigned long long)__double_as_longlong(*src);
     else *src = __longlong_as_double((long long)hist_row[i]);
 }
 
-// Does the training set fit the lanes' registers with this workgroup size?  (mirrors the dispatch below)
-bool ens_stream_fits(const alabi_ens* e) {
-    const int T = e->threads, half = e->gp->Npad / 2, db = dim_bucket(e->d);
-    const int ppt = (half + T - 1) / T;
-    if (T != 512 && T != 1024) return false;
-    if (ppt == 1) return db <= 24;
-    if (T == 512 && ppt == 2) return db <= 24;
-    if (T == 512 && ppt <= 4) return db <= 12;
-    return false;
+// After the persistent kernel: versions 1..K of every walker -> the (thinned) chain, and the acceptance counters.
+// One thread per (version, walker, word); a few MB at HBM speed per launch of K steps.
+__global__ void __launch_bounds__(256)
+ens_hist_chain_kernel(const unsigned long long* __restrict__ hist, int K, int WT, int d, int thin_by,
+                      const long long* __restrict__ run_state, const int* __restrict__ err, double* __restrict__ chain,
+                      double* __restrict__ chain_logp, unsigned long long* __restrict__ n_accept) {
+    if (*err) return;                                  // timed out: the rows are incomplete, the host reruns the chunk
+    const int row = d + 2;
+    const size_t n = (size_t)K * WT * row;
+    const long long done0 = run_state[1];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i % row);
+        const size_t vw = i / row;
+        const int w = (int)(vw % WT), v = (int)(vw / WT) + 1;
+        const unsigned long long word = hist[(size_t)WT * row + i];
+        if (k == d + 1) { if (word == 1ull && n_accept) atomicAdd(n_accept + w, 1ull); continue; }
+        const long long done = done0 + v;
+        if (done % thin_by != 0) continue;
+        const size_t slot = (size_t)(done / thin_by - 1);
+        if (k < d) { if (chain) chain[(slot * WT + w) * d + k] = __longlong_as_double((long long)word); }
+        else if (chain_logp) chain_logp[slot * WT + w] = __longlong_as_double((long long)word);
+    }
 }
+
+// Persistent-kernel configuration: T compute lanes (+ the hand-off wave and the record wave), PPT point pairs per lane.
+// The limits are the largest dimension buckets that compile without VGPR spills
+// (hipcc -Rpass-analysis=kernel-resource-usage; 256 VGPRs at 384 threads, 168 at 640).
+static int ens_stream_ppt(const alabi_ens* e) {
+    const int T = e->threads, half = e->gp->Npad / 2, db = dim_bucket(e->d);
+    if ((T != 256 && T != 512) || e->d > 61 || db < 0 || db > 16) return 0;
+    const int ppt = (half + T - 1) / T;
+    const bool generic = e->gp->kf.type != 0;
+    int max_db = 0;
+    if (T == 512) max_db = (ppt == 1) ? (generic ? 12 : 16) : (ppt == 2) ? (generic ? 6 : 10) : 0;
+    else max_db = (ppt <= 2) ? 16 : (ppt == 3) ? (generic ? 10 : 12) : (ppt == 4) ? (generic ? 6 : 10) : 0;
+    return db <= max_db ? ppt : 0;
+}
+
+bool ens_stream_fits(const alabi_ens* e) { return ens_stream_ppt(e) > 0; }
+
+#define ALABI_STREAM_DISPATCH_DIM(DB, ...)                            \
+    switch (DB) {                                                     \
+        case 1: { constexpr int D = 1; __VA_ARGS__; } break;          \
+        case 2: { constexpr int D = 2; __VA_ARGS__; } break;          \
+        case 3: { constexpr int D = 3; __VA_ARGS__; } break;          \
+        case 4: { constexpr int D = 4; __VA_ARGS__; } break;          \
+        case 5: { constexpr int D = 5; __VA_ARGS__; } break;          \
+        case 6: { constexpr int D = 6; __VA_ARGS__; } break;          \
+        case 8: { constexpr int D = 8; __VA_ARGS__; } break;          \
+        case 10: { constexpr int D = 10; __VA_ARGS__; } break;        \
+        case 12: { constexpr int D = 12; __VA_ARGS__; } break;        \
+        case 16: { constexpr int D = 16; __VA_ARGS__; } break;        \
+        default: return ALABI_BAD_ARGUMENT;                           \
+    }
+#define ALABI_STREAM_LAUNCH(PPT_, TMAX_)                                                                          \
+    ALABI_STREAM_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type,                                              \
+        hipLaunchKernelGGL((ens_stream_kernel<D, PPT_, TMAX_, GENERIC>), dim3(e->stream_grid, e->E), dim3(T + 128), 0, s, a)))
 
 int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
                       long long* n_accept, hipStream_t s) {
     alabi_gp* gp = e->gp;
-    const int WT = e->W * e->E, row = e->d + 1;
+    const int WT = e->W * e->E, row = e->d + 2;
     const int n0 = (e->W + 1) / 2;
     hipLaunchKernelGGL(ens_hist_fill_kernel, dim3(1024), dim3(256), 0, s, e->hist + (size_t)WT * row, (size_t)K * WT * row);
     hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp, e->hist, WT, e->d, 1);
@@ -515,16 +646,25 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
     a.K = K; a.W = e->W; a.n0 = n0; a.d = e->d; a.Npad = gp->Npad; a.thin_by = thin_by; a.spin_limit = 1 << 20;
     a.amp = exp(gp->log_amp); a.mean = gp->mean; a.kf = gp->kf;
     const int db = dim_bucket(e->d);
-    // lanes x pairs-per-lane must cover Npad/2 point pairs; the classic kernel's lane->point map (and therefore its
-    // summation order) is reproduced exactly when T == e->threads.
-    const int T = e->threads;
-    const int ppt = (gp->Npad / 2 + T - 1) / T;
-    if (ppt == 1) { ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((ens_stream_kernel<D, 1, 1024, GENERIC>), dim3(e->stream_grid, e->E), dim3(T), 0, s, a))); }
-    else if (ppt == 2 && T <= 512) { ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((ens_stream_kernel<D, 2, 512, GENERIC>), dim3(e->stream_grid, e->E), dim3(T), 0, s, a))); }
-    else if (ppt <= 4 && T <= 512 && db <= 12) { ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((ens_stream_kernel<D, 4, 512, GENERIC>), dim3(e->stream_grid, e->E), dim3(T), 0, s, a))); }
-    else return ALABI_BAD_ARGUMENT;
+    // lanes x pairs-per-lane cover Npad/2 point pairs; the launch-per-half-step kernel's lane -> point map (and so its
+    // summation order) is reproduced exactly because both run with e->threads compute lanes.
+    const int T = e->threads, ppt = ens_stream_ppt(e);
+    if (T == 256) {
+        if (ppt == 1) { ALABI_STREAM_LAUNCH(1, 384); }
+        else if (ppt == 2) { ALABI_STREAM_LAUNCH(2, 384); }
+        else if (ppt == 3) { ALABI_STREAM_LAUNCH(3, 384); }
+        else if (ppt == 4) { ALABI_STREAM_LAUNCH(4, 384); }
+        else return ALABI_BAD_ARGUMENT;
+    } else if (T == 512) {
+        if (ppt == 1) { ALABI_STREAM_LAUNCH(1, 640); }
+        else if (ppt == 2) { ALABI_STREAM_LAUNCH(2, 640); }
+        else return ALABI_BAD_ARGUMENT;
+    } else return ALABI_BAD_ARGUMENT;
     hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp,
                        e->hist + (size_t)K * WT * row, WT, e->d, 0);
+    if (chain || chain_logp || n_accept)
+        hipLaunchKernelGGL(ens_hist_chain_kernel, dim3(2048), dim3(256), 0, s, e->hist, K, WT, e->d, thin_by, e->run_state,
+                           e->err, chain, chain_logp, reinterpret_cast<unsigned long long*>(n_accept));
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

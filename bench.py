@@ -279,7 +279,10 @@ def main():
             chunk = min(args.mcmc_steps, 1024)
             launches_per_step = -(-args.mcmc_steps // chunk)
             flops_per_launch = 2.0 * chunk * n_prop * N * (2 * d + 3)
-            kernel_name = f"ens_stream_kernel<{d},1,1024>"
+            npad = -(-N // 64) * 64
+            lanes = 256 if npad // 2 <= 1024 else 1024            # alabi_ens_create's choice (api.hip)
+            lanes = int(os.environ.get("ALABI_ENS_THREADS", lanes))
+            kernel_name = f"ens_stream_kernel<{d},{-(-(npad // 2) // lanes)},{lanes + 128}>"
         else:
             flops_per_launch = n_prop * N * (2 * d + 3)
             kernel_name = f"ens_half_kernel<{d}>"
@@ -293,7 +296,8 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_by_kernel.json")
         if os.path.exists(pmc_path) and args.config == "C3" and args.ensembles == 1 and not shard:
             try:
-                pmc = json.load(open(pmc_path))["void alabi::" + kernel_name.split("<")[0] + ("<10, 1, 1024>" if path == "stream" else "<10>")]
+                allk = json.load(open(pmc_path))
+                pmc = next(v for k, v in allk.items() if k.startswith("void alabi::" + kernel_name.split("<")[0] + "<"))
                 # FETCH_SIZE is doubled only where the reads are 16-B-per-lane streams (the per-launch X loads of
                 # ens_half_kernel); the persistent kernel's fetches are 8-byte polls / row reads, counted as reported
                 fetch_corr = 1.0 if path == "stream" else 2.0
