@@ -41,6 +41,7 @@ SIGNATURES = {
     "alabi_gp_predict": (_i, [_vp, _vp, _ll, _vp, _vp, _vp]),
     "alabi_gp_logdet": (_i, [_vp, _pd, _vp]),
     "alabi_gp_nll": (_i, [_vp, _pd, _vp]),
+    "alabi_gp_grad_log_likelihood": (_i, [_vp, _pd, _vp]),
     "alabi_gp_get_alpha": (_i, [_vp, _vp, _vp]),
     "alabi_gp_get_factor": (_i, [_vp, _vp, _vp]),
     "alabi_gp_n": (_i, [_vp, _pi]),

@@ -413,12 +413,32 @@ class SurrogateModel(object):
                     v += gp_utils.regularization_term(p, self.hp_length_indices, amp_0=amp_0, mu_0=mu_0, sigma_0=sigma_0)
                 return v if np.isfinite(v) else 1e25
 
-            def grad_nll(p_opt, h=1e-5):
-                g = np.zeros(len(p_opt))
-                for i in range(len(p_opt)):
-                    e = np.zeros(len(p_opt)); e[i] = h
-                    g[i] = (nll(p_opt + e) - nll(p_opt - e)) / (2 * h)
-                return g
+            def grad_nll(p_opt):
+                """-d logL/dp from the device's analytic gradient (+ the regulariser's), assembled exactly as the
+                reference does (core.py:1255-1277): with uniform_scales the shared length-scale entry receives the MEAN
+                of the per-dimension gradients."""
+                p = self.expand_hyperparameter_vector(p_opt)
+                self.set_hyperparameter_vector(gp, p_opt)
+                try:
+                    grad_lnlike = -gp.grad_log_likelihood(_y, quiet=True)
+                except (np.linalg.LinAlgError, RuntimeError):
+                    return np.zeros(len(p_opt))
+                if not np.all(np.isfinite(grad_lnlike)):
+                    return np.zeros(len(p_opt))
+                if self.uniform_scales:
+                    gll = np.zeros(len(p_opt))
+                    gll[self.hp_length_index] = np.mean(grad_lnlike[self.hp_length_indices])
+                    gll[self.hp_other_indices] = grad_lnlike[self.hp_other_indices]
+                else:
+                    gll = grad_lnlike
+                if regularize:
+                    reg_grad = gp_utils.regularization_gradient(p, self.hp_length_indices, amp_0=amp_0, mu_0=mu_0,
+                                                                sigma_0=sigma_0)
+                    if self.uniform_scales:
+                        gll[self.hp_length_index] += np.mean(reg_grad[self.hp_length_indices])
+                    else:
+                        gll = gll + reg_grad
+                return gll
 
             use_grad = self.gp_opt_method in ("newton-cg", "l-bfgs-b")
             opts = dict(optimizer_kwargs)

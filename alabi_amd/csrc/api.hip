@@ -198,6 +198,19 @@ int alabi_gp_nll(alabi_gp* gp, double* out, void* stream) {
     return ALABI_OK;
 }
 
+int alabi_gp_grad_log_likelihood(alabi_gp* gp, double* grad_out, void* stream) {
+    if (!gp || !grad_out) return ALABI_BAD_ARGUMENT;
+    if (!gp->computed || !gp->has_alpha) return ALABI_NOT_COMPUTED;
+    hipStream_t s = as_stream(stream);
+    double* grad_dev = gp->work;                       // solve scratch, free once alpha exists (2 n_cap >= d + 4 doubles)
+    if (2 * (size_t)gp->n_cap < (size_t)gp->d + 4) return ALABI_BAD_ARGUMENT;
+    int st = launch_grad_log_likelihood(gp, grad_dev, s);
+    if (st != ALABI_OK) return st;
+    ALABI_HIP_CHECK(hipMemcpyAsync(grad_out, grad_dev, (size_t)(gp->d + 4) * sizeof(double), hipMemcpyDeviceToHost, s));
+    ALABI_HIP_CHECK(hipStreamSynchronize(s));
+    return ALABI_OK;
+}
+
 int alabi_gp_get_alpha(alabi_gp* gp, double* alpha_out, void* stream) {
     if (!gp || !alpha_out) return ALABI_BAD_ARGUMENT;
     if (!gp->computed || !gp->has_alpha) return ALABI_NOT_COMPUTED;

@@ -137,6 +137,8 @@ int launch_alpha(alabi_gp* gp, hipStream_t s);
 int launch_reductions(alabi_gp* gp, hipStream_t s);
 // gp_predict.hip
 int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu, hipStream_t s);
+int launch_factor_inverse(alabi_gp* gp, hipStream_t s);
+int launch_grad_log_likelihood(alabi_gp* gp, double* grad_dev, hipStream_t s);
 int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var,
                        hipStream_t s);
 // utility.hip

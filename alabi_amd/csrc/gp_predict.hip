@@ -78,7 +78,10 @@ predict_mean_tile_kernel(const double* __restrict__ Xt, const double* __restrict
     if (tid < 64 && m < M) mu[m] = fma(amp, (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]), mean);
 }
 
-template <int D>
+// IDENT = true turns the same blocked forward substitution into a triangular inversion: the right-hand side of
+// tile t is columns 64t..64t+63 of the identity, the V tiles are the OUTPUT (ws[t] = L^-1[:, 64t:64t+64] as
+// [Npad][64], rows above block t are never written nor read), and nothing else is produced.
+template <int D, bool IDENT = false>
 __global__ void __launch_bounds__(256, 2)
 predict_var_kernel(const double* __restrict__ L, const double* __restrict__ dinv, const double* __restrict__ Xt,
                    const double* __restrict__ alpha, int N, int Npad, const double* __restrict__ Xs, int d, long long M, DimVec inv_len,
@@ -100,23 +103,26 @@ predict_var_kernel(const double* __restrict__ L, const double* __restrict__ dinv
     const long long ntiles = (M + 63) / 64;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long m = tile * 64 + c;
+        if (IDENT) V = ws + (size_t)tile * Npad * 64;
+        const int kb0 = IDENT ? (int)tile : 0;       // first block row with a non-zero right-hand side
         double q[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) q[k] = (m < M && k < d) ? Xs[m * d + k] * inv_len.v[k] : 0.0;
+        for (int k = 0; k < D; ++k) q[k] = (!IDENT && m < M && k < d) ? Xs[m * d + k] * inv_len.v[k] : 0.0;
         double mu_acc = 0.0, ss = 0.0;
-        for (int kb = 0; kb < nb; ++kb) {
+        for (int kb = kb0; kb < nb; ++kb) {
             __syncthreads();   // the previous block's solve has finished with As / Vs / xtr / alb / dis
             // Software pipeline: the 64x64 L block and V tile of step j+1 travel HBM/L2 -> registers (16 B per
             // lane, 8 + 8 loads) while step j runs on the matrix cores; the first stage is issued here so
             // that the K* evaluation below hides it.
             f64x2 pa[8], pv[8];
             {
-                const double* Lb = L + (size_t)(kb * 64) * ld + (kb > 0 ? 0 : kb * 64);
+                const double* Lb = L + (size_t)(kb * 64) * ld + (kb > kb0 ? kb0 * 64 : kb * 64);
+                const double* V0 = V + (size_t)(kb0 * 64) * 64;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int e = tid + 256 * i, r = e >> 5, c2 = e & 31;
                     pa[i] = *reinterpret_cast<const f64x2*>(Lb + (size_t)r * ld + 2 * c2);
-                    if (kb > 0 && split != 1) pv[i] = reinterpret_cast<const f64x2*>(V)[e];
+                    if (kb > kb0 && split != 1) pv[i] = reinterpret_cast<const f64x2*>(V0)[e];
                 }
             }
             for (int e = tid; e < D * 64; e += 256) xtr[e >> 6][e & 63] = Xt[(size_t)(e >> 6) * Npad + kb * 64 + (e & 63)];
@@ -133,6 +139,7 @@ predict_var_kernel(const double* __restrict__ L, const double* __restrict__ dinv
                     r2 = fma(df, df, r2);
                 }
                 double kv = (kb * 64 + r < N) ? amp * radial(r2, kf) : 0.0;
+                if (IDENT) kv = (kb == kb0 && r == c) ? 1.0 : 0.0;
                 mu_acc = fma(kv, alb[r], mu_acc);
                 Vs[r][c] = kv;
             }
@@ -142,7 +149,7 @@ predict_var_kernel(const double* __restrict__ L, const double* __restrict__ dinv
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[n][i] = Vs[16 * w + lk + 4 * i][16 * n + lr];
-            for (int j = 0; j < kb; ++j) {
+            for (int j = kb0; j < kb; ++j) {
                 __syncthreads();       // every wave is done reading As / Vs
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -212,6 +219,7 @@ predict_var_kernel(const double* __restrict__ L, const double* __restrict__ dinv
         }
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
+        if (IDENT) continue;
         {
             const long long mc = tile * 64 + 16 * w + lr;
             if (lk == 0 && mc < M) var[mc] = amp - ss;
@@ -261,6 +269,26 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
     ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(predict_var_kernel<D>, dim3(grid), dim3(256), 0, s, gp->L, gp->dinv, gp->Xt,
                                               gp->alpha, gp->N, gp->Npad, Xs, gp->d, M, gp->inv_len, amp,
                                               gp->mean, gp->ws, mu, var, 0, gp->kf));
+    ALABI_LAUNCH_CHECK();
+    return ALABI_OK;
+}
+
+// L^-1 into the workspace, tile-major: ws[t] = L^-1[:, 64t:64t+64] as [Npad][64] (rows above block t unspecified).
+int launch_factor_inverse(alabi_gp* gp, hipStream_t s) {
+    const int nb = gp->Npad / 64;
+    const size_t need = (size_t)gp->Npad * gp->Npad * sizeof(double);
+    if (need > gp->ws_bytes) {
+        if (gp->ws) {
+            ALABI_HIP_CHECK(hipStreamSynchronize(s));
+            ALABI_HIP_CHECK(hipFree(gp->ws));
+            gp->ws = nullptr; gp->ws_bytes = 0;
+        }
+        ALABI_HIP_CHECK(hipMalloc(&gp->ws, need));
+        gp->ws_bytes = need;
+    }
+    hipLaunchKernelGGL((predict_var_kernel<1, true>), dim3(nb), dim3(256), 0, s, gp->L, gp->dinv, gp->Xt, gp->alpha, gp->N,
+                       gp->Npad, (const double*)nullptr, gp->d, (long long)gp->Npad, gp->inv_len, 1.0, 0.0, gp->ws,
+                       (double*)nullptr, (double*)nullptr, 0, gp->kf);
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

@@ -351,12 +351,31 @@ class HipGP:
     def nll(self, y):
         return -self.log_likelihood(y, quiet=True)
 
-    def grad_log_likelihood(self, y, quiet=False, h=1e-5):
-        """d logL / d p by central differences of the native likelihood (2 x len(p) factorisations).
+    def grad_log_likelihood(self, y, quiet=False):
+        """d logL / d p over the unfrozen vector (george protocol; reference call sites core.py:1261, gp_utils.py:165).
 
-        INTERIM: george's analytic 0.5 tr((aa^T - K^-1) dK/dp) needs a
-        K^-1 and dK/dp contraction kernel that is not written yet.
-        """
+        Analytic, on the device: 0.5 tr((alpha alpha^T - K^-1) dK/dp) with K^-1 = L^-T L^-1 formed block by block on the
+        matrix cores and contracted with the re-evaluated kernel derivatives (csrc/gp_grad.hip); one factorisation."""
+        if not self.recompute(quiet=quiet):
+            return np.zeros(len(self.get_parameter_vector()))      # george: quiet=True gives zeros when K is not PD
+        self._set_y(y)
+        out = (C.c_double * (self.ndim + 4))()
+        _lib.check(_lib.lib().alabi_gp_grad_log_likelihood(self._handle, out, _lib.current_stream()),
+                   "alabi_gp_grad_log_likelihood")
+        full = np.array(out[:], dtype=np.float64)
+        g = []
+        if self.fit_mean:
+            g.append(full[0])
+        if self.fit_white_noise:
+            g.append(full[1])
+        g.append(full[2])
+        if self.kernel_name == "RationalQuadraticKernel":
+            g.append(full[3])
+        g.extend(full[4:4 + self.ndim])
+        return np.array(g)
+
+    def grad_log_likelihood_fd(self, y, h=1e-5):
+        """Central differences of the native likelihood (2 x len(p) factorisations): the check for the analytic gradient."""
         p0 = self.get_parameter_vector()
         g = np.zeros_like(p0)
         for i in range(p0.size):

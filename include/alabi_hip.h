@@ -80,6 +80,13 @@ int alabi_gp_predict(alabi_gp* gp, const double* Xs, long long M, double* mu, do
 int alabi_gp_logdet(alabi_gp* gp, double* out, void* stream);
 int alabi_gp_nll(alabi_gp* gp, double* out, void* stream);
 
+/* d logL / d p of the log marginal likelihood at the current hyper-parameters, analytic:
+ * 0.5 tr((alpha alpha^T - K^-1) dK/dp) and sum(alpha) for the mean.  Replaces george's
+ * gp.grad_log_likelihood(y) (reference call sites alabi/core.py:1261, alabi/gp_utils.py:165).
+ * grad_out (HOST, d + 4 doubles): [mean, log white noise, log amplitude, log alpha (0 unless the kernel is the
+ * rational quadratic), log_M_0 .. log_M_{d-1}].  Needs alabi_gp_compute and alabi_gp_set_y.  Synchronises. */
+int alabi_gp_grad_log_likelihood(alabi_gp* gp, double* grad_out, void* stream);
+
 /* Inspection (tests, GP-protocol adapter: gp._alpha, utility.py:577; solver factor). */
 int alabi_gp_get_alpha(alabi_gp* gp, double* alpha_out /* [N] */, void* stream);
 int alabi_gp_get_factor(alabi_gp* gp, double* L_out /* [N,N] row-major, upper part zero */,

@@ -244,3 +244,26 @@ def test_full_size_configs_properties(torch_gpu):
     assert i >= 0 and abs(val - u_i) <= 1e-9 * abs(u_i)
     L = g.solver.get_factor()
     assert float(L.diagonal().min()) > 0 and abs(g.solver.log_determinant - 2 * float(L.diagonal().log().sum())) < 1e-6
+
+
+def test_grad_log_likelihood_analytic():
+    """alabi_gp_grad_log_likelihood vs the oracle's analytic gradient (sq-exp) and vs central differences of the device
+    likelihood (all four kernels); N not a multiple of 64 so the padded rows are exercised."""
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    X, y, h = make_problem(333, 5, 21, log_wn=-6.0)
+    g = HipGP(5, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+    o = OracleGP(5, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X)
+    ga, go = g.grad_log_likelihood(y), o.grad_log_likelihood(y)
+    assert ga.shape == go.shape == (8,)
+    np.testing.assert_allclose(ga, go, rtol=1e-8, atol=1e-8 * np.max(np.abs(go)))
+    for kernel in ("Matern32Kernel", "Matern52Kernel", "RationalQuadraticKernel"):
+        gk = HipGP(5, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"], kernel=kernel, log_alpha=0.3)
+        gk.compute(X)
+        an, fd = gk.grad_log_likelihood(y), gk.grad_log_likelihood_fd(y, h=1e-5)
+        assert an.shape == fd.shape
+        np.testing.assert_allclose(an, fd, rtol=2e-5, atol=2e-5 * np.max(np.abs(fd)))
+    # frozen parameters drop out of the vector (george protocol)
+    gf = HipGP(5, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"], fit_mean=False, fit_white_noise=False)
+    gf.compute(X)
+    np.testing.assert_allclose(gf.grad_log_likelihood(y), ga[2:], rtol=1e-12)
