@@ -19,6 +19,7 @@
 //                  per-workgroup HBM workspace (they do not fit in 160 KB of LDS) and are
 //                  re-read through L2.  N^2 flops per query (MFMA bound), L streamed once per
 //                  64-query tile.
+#include <cstdlib>
 #include "gp_device.hpp"
 
 namespace alabi {
@@ -266,9 +267,11 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
         gp->ws_bytes = need;
     }
     const double amp = exp(gp->log_amp);
+    int split = 0;   // ablation knob for tools/prof_predict.py only (results are wrong unless 0)
+    if (const char* env = getenv("ALABI_PV_ABLATE")) split = atoi(env);
     ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(predict_var_kernel<D>, dim3(grid), dim3(256), 0, s, gp->L, gp->dinv, gp->Xt,
                                               gp->alpha, gp->N, gp->Npad, Xs, gp->d, M, gp->inv_len, amp,
-                                              gp->mean, gp->ws, mu, var, 0, gp->kf));
+                                              gp->mean, gp->ws, mu, var, split, gp->kf));
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

@@ -89,6 +89,26 @@ def cpu_baseline_vectorized(cfg, budget_s=5.0):
                       "in one NumPy call (not the reference's call shape)"}
 
 
+def cpu_predict_baseline(cfg):
+    """GP-predict points/s of the NumPy/SciPy oracle (BLAS threads = library default): mean-only on 10^4 points and
+    mean+variance (cho_solve, as george does) on 2048 points of the same workload."""
+    from oracle.gp_oracle import OracleGP
+    h = cfg["hyper"]
+    gp = OracleGP(cfg["d"], h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(cfg["X"])
+    rs = np.random.RandomState(5)
+    lo, hi = cfg["bounds"][:, 0], cfg["bounds"][:, 1]
+    out = {}
+    for label, M, var in (("mean_pts_per_s", 10000, False), ("meanvar_pts_per_s", 2048, True)):
+        Xs = lo + (hi - lo) * rs.rand(M, cfg["d"])
+        gp.predict(cfg["y"], Xs[:64], return_var=var)
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < 1.5:
+            gp.predict(cfg["y"], Xs, return_var=var); n += 1
+        out[label] = M * n / (time.perf_counter() - t0)
+    out["sample"] = "oracle.OracleGP.predict: 10^4 points mean-only, 2048 points mean+variance; NumPy/SciPy default threads"
+    return out
+
+
 def cpu_baseline(cfg, budget_s=10.0, cores=1):
     """Reference-shaped CPU path (BASELINE.md B-ref): emcee's red-blue stretch move calling lnprob once per walker per
     half step (CachedSurrogateLikelihood route, alabi/core.py:53-122).  cores > 1 hands the per-walker calls to a
@@ -147,11 +167,12 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     # CPU baselines first: the multi-core one forks a pool, which must happen before the GPU is initialised
-    cpu_base = cpu_base_all = cpu_base_vec = None
+    cpu_base = cpu_base_all = cpu_base_vec = cpu_pred = None
     if world == 1 and not args.no_cpu_baseline:
         cfg0 = make_config(args.config, N=args.ntrain, W=args.walkers)
         cpu_base = cpu_baseline(cfg0, budget_s=10.0, cores=1)
         cpu_base_vec = cpu_baseline_vectorized(cfg0, budget_s=5.0)
+        cpu_pred = cpu_predict_baseline(cfg0)
         ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         ncores = max(1, min(ncores, 64))
         if ncores > 1:
@@ -293,7 +314,7 @@ def main():
         # MI355X_MICROARCH.md section HBM).  A PMC pass cannot run inside this process, so the number is read from
         # profiles/ and is null when the file is absent or the workload differs from the profiled one.
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_by_kernel.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_by_kernel.json")
         if os.path.exists(pmc_path) and args.config == "C3" and args.ensembles == 1 and not shard:
             try:
                 allk = json.load(open(pmc_path))
@@ -301,9 +322,12 @@ def main():
                 # FETCH_SIZE is doubled only where the reads are 16-B-per-lane streams (the per-launch X loads of
                 # ens_half_kernel); the persistent kernel's fetches are 8-byte polls / row reads, counted as reported
                 fetch_corr = 1.0 if path == "stream" else 2.0
-                traffic = (fetch_corr * pmc["FETCH_SIZE"]["mean_KB"] + pmc["WRITE_SIZE"]["mean_KB"]) * 1024.0
-                if path == "stream":   # the PMC pass profiled launches of `pmc_steps` steps: scale to this launch
-                    traffic *= min(args.mcmc_steps, 1024) / float(pmc.get("steps_per_launch", min(args.mcmc_steps, 1024)))
+                # the persistent kernel's full launches are the largest ones (1024 steps); shorter first/last launches
+                # would dilute a mean
+                key = "max_KB" if (path == "stream" and "max_KB" in pmc["FETCH_SIZE"]) else "mean_KB"
+                traffic = (fetch_corr * pmc["FETCH_SIZE"][key] + pmc["WRITE_SIZE"][key]) * 1024.0
+                if path == "stream":   # PMC launches cover `steps_per_launch` steps (1024 unless stated): scale to this launch
+                    traffic *= min(args.mcmc_steps, 1024) / float(pmc.get("steps_per_launch", 1024))
             except Exception:  # noqa: BLE001
                 traffic = None
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -323,11 +347,13 @@ def main():
             gp.predict_device(y_dev, torch.as_tensor(cfg["X"][:1], device="cuda"))
             gen = torch.Generator(device="cuda"); gen.manual_seed(1)
             lo = torch.as_tensor(cfg["bounds"][:, 0], device="cuda"); hi = torch.as_tensor(cfg["bounds"][:, 1], device="cuda")
-            for label, M, var in (("predict_mean_pts_per_s_M1e6", 1_000_000, False), ("predict_mean_pts_per_s_M256", 256, False),
-                                  ("predict_meanvar_pts_per_s_M65536", 65536, True)):
+            for label, M, var in (("predict_mean_pts_per_s_M1e6", 1_000_000, False), ("predict_mean_pts_per_s_M1e4", 10_000, False),
+                                  ("predict_mean_pts_per_s_M256", 256, False), ("predict_meanvar_pts_per_s_M1e6", 1_000_000, True),
+                                  ("predict_meanvar_pts_per_s_M65536", 65536, True), ("predict_meanvar_pts_per_s_M1e4", 10_000, True),
+                                  ("predict_meanvar_pts_per_s_M256", 256, True)):
                 Xs = lo + (hi - lo) * torch.rand((M, d), dtype=torch.float64, device="cuda", generator=gen)
                 gp.predict_device(y_dev, Xs, return_var=var); torch.cuda.synchronize()
-                reps = 3 if M > 1000 else 200
+                reps = (2 if var else 3) if M > 100000 else (20 if M > 1000 else 200)
                 t1 = time.perf_counter()
                 for _ in range(reps):
                     gp.predict_device(y_dev, Xs, return_var=var)
@@ -349,6 +375,8 @@ def main():
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
             out["speedup_vs_cpu_baseline"] = value / cpu_base["value"]
+            if cpu_pred is not None:
+                out["cpu_baseline_predict"] = cpu_pred
             if cpu_base_vec is not None:
                 out["cpu_baseline_vectorized"] = cpu_base_vec
                 out["speedup_vs_cpu_baseline_vectorized"] = value / cpu_base_vec["value"]
