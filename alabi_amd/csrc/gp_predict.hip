@@ -20,6 +20,14 @@
 //                  re-read through L2.  N^2 flops per query (MFMA bound), L streamed once per
 //                  64-query tile.
 #include <cstdlib>
+// Compile-time ablation switches of the wave-specialised variance kernel (timing only, results are wrong when set):
+// -DALABI_PV_NO_MFMA=1 removes the matrix-core work, -DALABI_PV_NO_LOADS=1 the steady-state global loads.
+#ifndef ALABI_PV_NO_MFMA
+#define ALABI_PV_NO_MFMA 0
+#endif
+#ifndef ALABI_PV_NO_LOADS
+#define ALABI_PV_NO_LOADS 0
+#endif
 #include "gp_device.hpp"
 
 namespace alabi {
@@ -232,6 +240,263 @@ predict_var_kernel(const double* __restrict__ L, const double* __restrict__ dinv
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-specialised variance kernel (the one launch_predict_var uses for d <= 16).  Same algorithm and data layout as
+// predict_var_kernel above -- per 64-query tile a blocked forward substitution V = L^-1 K*^T, off-diagonal updates on the
+// fp64 matrix cores -- but the workgroup is split into producers and consumers so that memory traffic and MFMA work overlap
+// (ablation of the kernel above at N=2000, M=65536: MFMA alone 3.3 ms, loads + LDS staging + solves alone 4.15 ms,
+// together 7.0 ms: they were serialised by the two barriers of every step).
+//
+//   768 threads, ONE workgroup per CU (LDS: two full stages, 155 KB).
+//   waves 0-3 (consumers)  run the 64 MFMAs of a stage out of LDS buffer b&1, and the 64x64 diagonal solve at the end of a
+//                          block row; nothing else.
+//   waves 4-11 (producers) stream the flattened stage sequence (kb, s), s = kb0..kb (s == kb: the diagonal block):
+//                          global -> registers two stages ahead, registers -> LDS buffer (b+1)&1 while the consumers work on
+//                          stage b; during a diagonal solve they evaluate the K* block of block row kb+2 and park it in
+//                          the workspace rows where V_{kb+2} will later be written (the consumers fetch it as their next
+//                          accumulator while they solve).
+//   One barrier per stage (two in a diagonal stage).  V_s must exist before a producer loads it: a stage whose V block is
+//   not finished yet gets its V part issued late; the one stage that needs V the moment it is produced (block row kb0+1)
+//   receives it from the consumers through LDS directly.
+// Pointer parameters of a (non-inlined) device function are generic: loads through them are FLAT instructions, which
+// count on the LDS counter as well and would serialise the prefetch pipeline with every LDS access.  The role functions
+// therefore cast their buffer pointers to the global address space first.
+typedef const double __attribute__((address_space(1)))* ws_gcptr;
+typedef double __attribute__((address_space(1)))* ws_gptr;
+typedef const f64x2 __attribute__((address_space(1)))* ws_gcptr2;
+// Module-scope LDS (two full stages): named directly by the role functions, so every access stays an LDS instruction
+// (passed as pointer arguments they degrade to generic pointers: 64-bit address arithmetic and a null check per access).
+__shared__ double ws_As[2][64][66];
+__shared__ double ws_Vs[2][64][80];
+__shared__ double ws_dis[2][64];
+
+// Producer waves of one tile.  Separate noinline functions per role: compiled as one body, the register allocator
+// merges the live ranges of both roles and spills hundreds of VGPRs.  No store and no spill may sit in the stage loop: on
+// gfx950 loads and stores share one counter, and with both kinds pending the compiler can only wait for ALL of them
+// (vmcnt(0)), which would drain the stage that is meant to stay in flight.
+__device__ __attribute__((noinline)) void
+ws_produce_tile(const double* L_, const double* dinv_, int Npad, const double* V_) {
+    const ws_gcptr L = (ws_gcptr)L_, dinv = (ws_gcptr)dinv_, V = (ws_gcptr)V_;
+    const int t8 = threadIdx.x - 256;          // 256 producer threads: 8 + 8 loads per stage each
+    const int nb = Npad / 64, ld = Npad, nstages = nb * (nb + 1) / 2;
+    // Two register sets; every stage issues exactly 8 + 8 + 1 loads (a diagonal stage loads a V block it does not use), so
+    // the wait for the OLDER set is a constant vmcnt and the younger set stays in flight.
+    f64x2 pa[2][8], pv[2][8];
+    double pd[2];
+#define ALABI_WS_ISSUE(SET, KB, S)                                                                            \
+    {                                                                                                         \
+        const ws_gcptr Lb_ = L + (size_t)((KB) * 64) * ld + (S) * 64;                                         \
+        const ws_gcptr2 Vj_ = (ws_gcptr2)(V + (size_t)(((S) < (KB) ? (S) : 0) * 64) * 64);                    \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                       \
+            const int e = t8 + 256 * i, r = e >> 5, c2 = e & 31;                                              \
+            pa[SET][i] = *(ws_gcptr2)(Lb_ + (size_t)r * ld + 2 * c2);                                         \
+            pv[SET][i] = Vj_[e];                                                                              \
+        }                                                                                                     \
+        pd[SET] = dinv[(KB) * 64 + (t8 & 63)];                                                                \
+    }
+#define ALABI_WS_TO_LDS(SET, BUF, WITH_V)                                                                     \
+    {                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                       \
+            const int e = t8 + 256 * i, r = e >> 5, c2 = e & 31;                                              \
+            *reinterpret_cast<f64x2*>(&ws_As[BUF][r][2 * c2]) = pa[SET][i];                                   \
+            if (WITH_V) *reinterpret_cast<f64x2*>(&ws_Vs[BUF][r][2 * c2]) = pv[SET][i];                       \
+        }                                                                                                     \
+        if (t8 < 64) ws_dis[BUF][t8] = pd[SET];                                                               \
+    }
+#define ALABI_WS_ADVANCE(KB, S) { if (++(S) > (KB)) { ++(KB); (S) = 0; } }
+    // ---- phase A: block rows 0..3, one stage at a time (a V block may be needed a stage or two after it is produced) ----
+    int b = 0, kb = 0, sj = 0;                 // the stage the consumers are working on
+    ALABI_WS_ISSUE(0, 0, 0)
+    ALABI_WS_TO_LDS(0, 0, false)
+    __syncthreads();                           // stage 0 is in LDS
+    int k1 = 0, s1 = 0;                        // stage b + 1
+    ALABI_WS_ADVANCE(k1, s1)
+    while (b < nstages && kb < 4) {
+        const int nbuf = (b & 1) ^ 1;
+        const bool diag = sj == kb;
+        if (b > 0) __syncthreads();            // stage b is in LDS buffer b & 1; buffer nbuf is free
+        if (diag) __syncthreads();             // the consumers' mid-stage barrier
+        if (b + 1 < nstages) {
+            ALABI_WS_ISSUE(0, k1, s1)
+            // stage (1, 0) needs V_0 the moment it is produced: the consumers hand it over in LDS themselves
+            ALABI_WS_TO_LDS(0, nbuf, (s1 < k1 && b > 0))
+        }
+        ++b;
+        ALABI_WS_ADVANCE(kb, sj)
+        ALABI_WS_ADVANCE(k1, s1)
+    }
+    // ---- phase B: block rows >= 4, two stages ahead.  Set 1 holds stage b + 1 for even b - bA, set 0 for odd. ----
+    if (b < nstages) {
+        // here (kb, sj) = (4, 0) = stage b (already in LDS), (k1, s1) = stage b + 1
+        int k2 = k1, s2 = s1;
+        ALABI_WS_ADVANCE(k2, s2)               // stage b + 2
+        ALABI_WS_ISSUE(1, k1, s1)
+        ALABI_WS_ISSUE(0, k2, s2)
+        int k3 = k2, s3 = s2;                  // stage b + 3, clamped to the last stage (harmless reloads at the very end)
+#define ALABI_WS_STAGE(NSET)                                                                                  \
+        {                                                                                                     \
+            const int nbuf = (b & 1) ^ 1;                                                                     \
+            const bool diag = sj == kb;                                                                       \
+            __syncthreads();               /* stage b is in LDS buffer b & 1; buffer nbuf is free */          \
+            if (diag) __syncthreads();     /* the consumers' mid-stage barrier */                             \
+            ALABI_WS_TO_LDS(NSET, nbuf, true)                                                                 \
+            if (k3 < nb - 1 || s3 < k3) ALABI_WS_ADVANCE(k3, s3)                                              \
+            if (!ALABI_PV_NO_LOADS) ALABI_WS_ISSUE(NSET, k3, s3)                                              \
+            ++b;                                                                                              \
+            ALABI_WS_ADVANCE(kb, sj)                                                                          \
+        }
+        while (b < nstages) {
+            ALABI_WS_STAGE(1)
+            if (b >= nstages) break;
+            ALABI_WS_STAGE(0)
+        }
+#undef ALABI_WS_STAGE
+    }
+#undef ALABI_WS_ISSUE
+#undef ALABI_WS_TO_LDS
+#undef ALABI_WS_ADVANCE
+}
+
+// Consumer waves of one tile: returns this lane's share of |L^-1 k*|^2 (before the cross-lane fold).
+__device__ __attribute__((noinline)) double
+ws_consume_tile(int Npad, double* V_) {
+    const ws_gptr V = (ws_gptr)V_;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
+    const int lr = lane & 15, lk = lane >> 4;  // MFMA lane decomposition
+    const int nb = Npad / 64;
+    double ss = 0.0;
+    __syncthreads();                   // stage 0 is in LDS
+    v4f64 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[n][i] = V[(size_t)(16 * w + lk + 4 * i) * 64 + 16 * n + lr];
+    int b = 0;
+    for (int kb = 0; kb < nb; ++kb)
+        for (int sj = 0; sj <= kb; ++sj, ++b) {
+            const int buf = b & 1, nbuf = buf ^ 1;
+            if (b > 0) __syncthreads();    // stage b is in LDS buffer buf
+            if (sj < kb) {
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const double a = -ws_As[buf][16 * w + lr][4 * ks + lk];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const double bb = ws_Vs[buf][4 * ks + lk][16 * n + lr];
+                        if (!ALABI_PV_NO_MFMA) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[n], 0, 0, 0);
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ws_Vs[buf][16 * w + lk + 4 * i][16 * n + lr] = acc[n][i];
+            if (kb + 1 < nb) {             // next block row's accumulator seed (K* rows parked by the producers)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[n][i] = V[(size_t)((kb + 1) * 64 + 16 * w + lk + 4 * i) * 64 + 16 * n + lr];
+            }
+            __syncthreads();
+            // diagonal solve: wave w owns columns 16w..16w+15; lane (col lr, group lk) holds rows == lk (mod 4)
+            const int col = 16 * w + lr;
+            double v[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] = ws_Vs[buf][4 * t + lk][col];
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                const int owner = r & 3, t = r >> 2;
+                double x = v[t] * ws_dis[buf][r];
+                x = __shfl(x, lr + 16 * owner, 64);
+                // rows of the pivot's own group of four: lanes below the pivot are done (select, no branch: straight-line
+                // code); every later group takes the update unconditionally
+                const double a_own = ws_As[buf][4 * t + lk][r];
+                v[t] = (lk == owner) ? x : ((lk > owner) ? fma(-a_own, x, v[t]) : v[t]);
+#pragma unroll
+                for (int t2 = t + 1; t2 < 16; ++t2) v[t2] = fma(-ws_As[buf][4 * t2 + lk][r], x, v[t2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                V[(size_t)(kb * 64 + 4 * t + lk) * 64 + col] = v[t];
+                if (kb == 0) ws_Vs[nbuf][4 * t + lk][col] = v[t];   // stage (1, 0) follows at once: hand V_0 over in LDS
+                ss = fma(v[t], v[t], ss);
+            }
+        }
+    return ss;
+}
+
+// K* pre-pass of the wave-specialised variance path: one workgroup per 64-query tile writes the tile's K* block
+// (Npad x 64, the accumulator seeds of every block row) into the tile's workspace and the predictive mean; the training
+// points are staged 256 at a time in LDS exactly as in predict_mean_tile_kernel.
+template <int D, bool GENERIC>
+__global__ void __launch_bounds__(256)
+predict_kstar_tile_kernel(const double* __restrict__ Xt, const double* __restrict__ alpha, int N, int Npad,
+                          const double* __restrict__ Xs, int d, long long M, DimVec inv_len, double amp, double mean,
+                          KernelFn kf, double* __restrict__ ws, double* __restrict__ mu) {
+    __shared__ double xt[D][256];
+    __shared__ double al[256];
+    __shared__ double part[4][64];
+    const int tid = threadIdx.x, c = tid & 63, w = tid >> 6;
+    const long long m = (long long)blockIdx.x * 64 + c;
+    double* V = ws + (size_t)blockIdx.x * Npad * 64;
+    double q[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[k] = (m < M && k < d) ? Xs[m * d + k] * inv_len.v[k] : 0.0;
+    double acc = 0.0;
+    for (int n0 = 0; n0 < Npad; n0 += 256) {
+        __syncthreads();
+        const int n = n0 + tid;
+#pragma unroll
+        for (int k = 0; k < D; ++k) xt[k][tid] = (n < Npad) ? Xt[(size_t)k * Npad + n] : 0.0;
+        al[tid] = (n < Npad) ? alpha[n] : 0.0;
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < 64; ++j) {
+            const int nn = w * 64 + j;
+            if (n0 + nn >= Npad) break;                    // workgroup-uniform per wave
+            double r2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double df = xt[k][nn] - q[k];
+                r2 = fma(df, df, r2);
+            }
+            const double kv = (n0 + nn < N) ? amp * radial<GENERIC>(r2, kf) : 0.0;
+            acc = fma(kv, al[nn], acc);
+            V[(size_t)(n0 + nn) * 64 + c] = kv;
+        }
+    }
+    part[w][c] = acc;
+    __syncthreads();
+    if (tid < 64 && m < M) mu[m] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + mean;
+}
+
+// One workgroup per CU walks over the tiles; tile t owns workspace rows ws[t] (K* seeds in, V out).
+__global__ void __launch_bounds__(512)
+predict_var_ws_kernel(const double* __restrict__ L, const double* __restrict__ dinv, int Npad, long long M, double amp,
+                      double* __restrict__ ws, double* __restrict__ var) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const long long ntiles = (M + 63) / 64;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        double* V = ws + (size_t)tile * Npad * 64;
+        __syncthreads();                       // the previous tile is completely finished with the LDS stages
+        if (wv >= 4) {
+            ws_produce_tile(L, dinv, Npad, V);
+        } else {
+            double ss = ws_consume_tile(Npad, V);
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const long long mc = tile * 64 + 16 * wv + lr;
+            if (lk == 0 && mc < M) var[mc] = amp - ss;
+        }
+    }
+}
+
 int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu, hipStream_t s) {
     if (M <= 0) return ALABI_OK;
     const int db = dim_bucket(gp->d);
@@ -255,6 +520,44 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
     if (M <= 0) return ALABI_OK;
     const int db = dim_bucket(gp->d);
     const long long tiles = (M + 63) / 64;
+    const char* legacy = getenv("ALABI_PV_LEGACY");
+    const bool ws_kernel = db <= 16 && !(legacy && legacy[0] == '1');
+    const double amp = exp(gp->log_amp);
+    if (ws_kernel) {
+        // wave-specialised path: every tile owns Npad x 64 doubles of workspace (K* seeds in, V out); queries are processed
+        // in chunks so that the workspace stays around 2 GiB (131072 queries at N = 2048)
+        int dev = 0, n_cu = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        // tiles per chunk: a whole number of rounds over the CUs within ~2 GiB of workspace (at least one round)
+        long long chunk_tiles = (2LL << 30) / ((long long)gp->Npad * 64 * 8);
+        chunk_tiles = chunk_tiles / n_cu * n_cu;
+        if (chunk_tiles < n_cu) chunk_tiles = n_cu;
+        long long chunk = chunk_tiles * 64;                                       // queries per chunk
+        if (chunk > M) chunk = (M + 63) / 64 * 64;
+        const size_t need = (size_t)(chunk / 64) * gp->Npad * 64 * sizeof(double);
+        if (need > gp->ws_bytes) {
+            if (gp->ws) {
+                ALABI_HIP_CHECK(hipStreamSynchronize(s));
+                ALABI_HIP_CHECK(hipFree(gp->ws));
+                gp->ws = nullptr; gp->ws_bytes = 0;
+            }
+            ALABI_HIP_CHECK(hipMalloc(&gp->ws, need));
+            gp->ws_bytes = need;
+        }
+        for (long long m0 = 0; m0 < M; m0 += chunk) {
+            const long long mc = (M - m0 < chunk) ? M - m0 : chunk;
+            const long long tiles_c = (mc + 63) / 64;
+            ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_kstar_tile_kernel<D, GENERIC>),
+                dim3((unsigned)tiles_c), dim3(256), 0, s, gp->Xt, gp->alpha, gp->N, gp->Npad, Xs + m0 * gp->d, gp->d, mc,
+                gp->inv_len, amp, gp->mean, gp->kf, gp->ws, mu + m0)));
+            const int grid_c = (int)(tiles_c < n_cu ? tiles_c : n_cu);
+            hipLaunchKernelGGL(predict_var_ws_kernel, dim3(grid_c), dim3(512), 0, s, gp->L, gp->dinv, gp->Npad, mc, amp, gp->ws,
+                               var + m0);
+        }
+        ALABI_LAUNCH_CHECK();
+        return ALABI_OK;
+    }
     const int grid = (int)(tiles < 512 ? tiles : 512);
     const size_t need = (size_t)grid * gp->Npad * 64 * sizeof(double);
     if (need > gp->ws_bytes) {
@@ -266,7 +569,6 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
         ALABI_HIP_CHECK(hipMalloc(&gp->ws, need));
         gp->ws_bytes = need;
     }
-    const double amp = exp(gp->log_amp);
     int split = 0;   // ablation knob for tools/prof_predict.py only (results are wrong unless 0)
     if (const char* env = getenv("ALABI_PV_ABLATE")) split = atoi(env);
     ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(predict_var_kernel<D>, dim3(grid), dim3(256), 0, s, gp->L, gp->dinv, gp->Xt,
