@@ -533,6 +533,7 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
         long long chunk_tiles = (2LL << 30) / ((long long)gp->Npad * 64 * 8);
         chunk_tiles = chunk_tiles / n_cu * n_cu;
         if (chunk_tiles < n_cu) chunk_tiles = n_cu;
+        if (const char* env = getenv("ALABI_PV_CHUNK_TILES")) { const long long v = atoll(env); if (v > 0) chunk_tiles = v; }   // tests
         long long chunk = chunk_tiles * 64;                                       // queries per chunk
         if (chunk > M) chunk = (M + 63) / 64 * 64;
         const size_t need = (size_t)(chunk / 64) * gp->Npad * 64 * sizeof(double);

@@ -267,3 +267,54 @@ def test_grad_log_likelihood_analytic():
     gf = HipGP(5, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"], fit_mean=False, fit_white_noise=False)
     gf.compute(X)
     np.testing.assert_allclose(gf.grad_log_likelihood(y), ga[2:], rtol=1e-12)
+
+
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 128, 200, 256, 257, 320, 400, 700])
+def test_predict_variance_block_row_boundaries(N):
+    """The wave-specialised variance kernel runs block rows 0..3 one stage at a time and later rows two stages ahead:
+    training-set sizes on both sides of every boundary (1, 2, 4, 5, 7, 11 block rows, ragged last block)."""
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    X, y, h = make_problem(N, 3, 100 + N, log_wn=-8.0)
+    if N == 1:
+        h["log_amp"] = 0.3
+    g = HipGP(3, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+    o = OracleGP(3, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X)
+    Xs = np.random.RandomState(N).uniform(-3.2, 3.2, (1000, 3))          # 16 tiles, the last one ragged
+    mu, var = g.predict(y, Xs, return_var=True)
+    mu_o, var_o = o.predict(y, Xs, return_var=True)
+    amp = np.exp(h["log_amp"])
+    assert np.max(np.abs(mu - mu_o) / (np.abs(mu_o) + 1)) <= 1e-9
+    assert np.max(np.abs(var - var_o)) <= 1e-7 * amp
+
+
+def test_predict_variance_paths_agree(monkeypatch):
+    """Chunked launches (several rounds of tiles), the legacy kernel (ALABI_PV_LEGACY=1, also used for d > 16) and the
+    default path give the same variances to rounding; d = 20 exercises the legacy dispatch on its own."""
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    X, y, h = make_problem(500, 6, 8, log_wn=-8.0)
+    Xs = np.random.RandomState(3).uniform(-3, 3, (5000, 6))
+    out = {}
+    for tag, env in (("default", {}), ("chunked", {"ALABI_PV_CHUNK_TILES": "7"}), ("legacy", {"ALABI_PV_LEGACY": "1"})):
+        for k in ("ALABI_PV_CHUNK_TILES", "ALABI_PV_LEGACY"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = HipGP(6, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+        out[tag] = g.predict(y, Xs, return_var=True)
+    amp = np.exp(h["log_amp"])
+    np.testing.assert_array_equal(out["default"][1], out["chunked"][1])
+    np.testing.assert_array_equal(out["default"][0], out["chunked"][0])
+    assert np.max(np.abs(out["default"][1] - out["legacy"][1])) <= 1e-9 * amp
+    assert np.max(np.abs(out["default"][0] - out["legacy"][0])) <= 1e-9 * (np.max(np.abs(out["legacy"][0])) + 1)
+    for k in ("ALABI_PV_CHUNK_TILES", "ALABI_PV_LEGACY"):
+        monkeypatch.delenv(k, raising=False)
+    X2, y2, h2 = make_problem(300, 20, 9, log_wn=-8.0, ell2=20.0)
+    g2 = HipGP(20, h2["mean"], h2["log_white_noise"], h2["log_amp"], h2["log_M"]); g2.compute(X2)
+    o2 = OracleGP(20, h2["mean"], h2["log_white_noise"], h2["log_amp"], h2["log_M"]).compute(X2)
+    Xs2 = np.random.RandomState(4).uniform(-3, 3, (300, 20))
+    mu2, var2 = g2.predict(y2, Xs2, return_var=True)
+    mu_o, var_o = o2.predict(y2, Xs2, return_var=True)
+    assert np.max(np.abs(mu2 - mu_o) / (np.abs(mu_o) + 1)) <= 1e-9
+    assert np.max(np.abs(var2 - var_o)) <= 1e-7 * np.exp(h2["log_amp"])
