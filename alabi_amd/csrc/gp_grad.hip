@@ -21,7 +21,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // f(r2) and f'(r2) of the four kernels (gp_device.hpp: radial)
 __device__ inline void radial_with_derivative(double r2, KernelFn kf, double& f, double& df, double& dlog_alpha) {
     dlog_alpha = 0.0;
-    if (kf.type == 0) { f = exp(-0.5 * r2); df = -0.5 * f; return; }
+    if (kf.type == 0) { f = exp_neg_half(r2); df = -0.5 * f; return; }
     if (kf.type == 1) { const double r = sqrt(3.0 * r2), e = exp(-r); f = (1.0 + r) * e; df = -1.5 * e; return; }
     if (kf.type == 2) {
         const double r = sqrt(5.0 * r2), e = exp(-r);
