@@ -423,34 +423,46 @@ ens_stream_kernel(StreamArgs p) {
     }
     __syncthreads();
     int t = 0, split = 0, bb = b, item = 0;           // b < G <= n0: the first item is valid
+    // Wave 0 idles while the compute waves work: it uses that time to decode the NEXT proposal's record and to form the
+    // addresses it will poll and store to, so that nothing but the accept test separates barrier B from the row store and
+    // the store from the next poll.
+    int n_w = 0; double n_zz = 0.0, n_lnfac = 0.0, n_lnu = 0.0;
+    const unsigned long long *n_hw = p.hist, *n_hc = p.hist;
+    auto decode_next = [&](int it, int tt, int sp) {
+        const unsigned long long* rs = rec_s[it & 3];
+        const unsigned long long ids = rs[0];
+        n_w = (int)(unsigned)(ids & 0xffffffffull);
+        const int cw = (int)(unsigned)(ids >> 32);
+        n_zz = __longlong_as_double((long long)rs[1]);
+        n_lnfac = __longlong_as_double((long long)rs[2]); n_lnu = __longlong_as_double((long long)rs[3]);
+        // own row at version t, partner row at version t (+1 when the partner's half went first)
+        n_hw = p.hist + ((size_t)tt * WT + n_w) * row + lane;
+        n_hc = p.hist + ((size_t)(tt + sp) * WT + cw) * row + lane;
+    };
+    if (comm) decode_next(0, 0, 0);
     while (t < p.K) {
         int t2 = t, s2 = split, b2 = bb;
         next_item(t2, s2, b2);
         const int par = item & 1;
-        int w = 0;
+        int w = 0, all_in = 0;
         double qv = 0.0, sv = 0.0, lnfac = 0.0, lnu = 0.0;   // wave 0; lane k < d: coordinate k, lane d: logp
 #ifdef ALABI_STREAM_PROF
         const long long c0 = clock64(); long long c1 = c0;
 #endif
+        unsigned long long* out_row = nullptr;
         if (comm) {
-            const unsigned long long* rs = rec_s[item & 3];
-            const unsigned long long ids = rs[0];
-            w = (int)(unsigned)(ids & 0xffffffffull);
-            const int cw = (int)(unsigned)(ids >> 32);
-            const double zz = __longlong_as_double((long long)rs[1]);
-            lnfac = __longlong_as_double((long long)rs[2]); lnu = __longlong_as_double((long long)rs[3]);
+            w = n_w; lnfac = n_lnfac; lnu = n_lnu;
+            const double zz = n_zz;
+            const unsigned long long *hw = n_hw, *hc = n_hc;    // this lane's words of the two rows
             const double il_r = consts_s[0][lane], lo_r = consts_s[1][lane], hi_r = consts_s[2][lane];
-            // own row at version t, partner row at version t (+1 when the partner's half went first)
-            const unsigned long long* hw = p.hist + ((size_t)t * WT + w) * row;
-            const unsigned long long* hc = p.hist + ((size_t)(t + split) * WT + cw) * row;
             // The data IS the flag (Guideline 16 form R2): every word of a row is one aligned 8-byte sc1 store
             // over a sentinel NaN that no coordinate or log-probability can equal; lane k polls its own words.
             unsigned long long ws = ALABI_HIST_EMPTY, wc = ALABI_HIST_EMPTY;
             int ok = 1, spins = 0;
             const bool mine = lane <= p.d, needc = lane < p.d;
             while (true) {
-                if (mine && ws == ALABI_HIST_EMPTY) ws = ld_sc1(hw + lane);
-                if (needc && wc == ALABI_HIST_EMPTY) wc = ld_sc1(hc + lane);
+                if (mine && ws == ALABI_HIST_EMPTY) ws = ld_sc1(hw);
+                if (needc && wc == ALABI_HIST_EMPTY) wc = ld_sc1(hc);
                 const int ready = (!mine || ws != ALABI_HIST_EMPTY) && (!needc || wc != ALABI_HIST_EMPTY);
                 if (__all(ready)) break;
                 if (++spins > p.spin_limit ||
@@ -473,10 +485,10 @@ ens_stream_kernel(StreamArgs p) {
                     qs = qv * il_r;
                 }
             }
-            const int all_in = ok ? __all(inb) : 0;
+            all_in = ok ? __all(inb) : 0;
             if (lane < D) qs_s[par][lane] = qs;
+            if (lane == 63) qs_s[par][63] = all_in ? 1.0 : 0.0;   // the in-bounds flag travels with the proposal (D <= 16)
             if (lane == 0) {
-                ctl_s[par][0] = all_in;
                 if (!ok) {                            // bounded spin ran out: every workgroup leaves, the host falls back
                     ctl_s[0][1] = 1;
                     __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -487,15 +499,16 @@ ens_stream_kernel(StreamArgs p) {
 #ifdef ALABI_STREAM_PROF
         const long long c2 = clock64();
 #endif
-        const int all_in = ctl_s[par][0];
+        double qraw[D];                               // one batch of LDS reads: the proposal and its in-bounds flag
+#pragma unroll
+        for (int k = 0; k < D; ++k) qraw[k] = qs_s[par][k];
+        if (!comm) all_in = __builtin_amdgcn_readfirstlane(__double2hiint(qs_s[par][63])) != 0;
         if (compute && all_in) {
             double q[D];                              // wave-uniform: moved to SGPRs
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const double qk = qs_s[par][k];
-                q[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(qk)),
-                                        __builtin_amdgcn_readfirstlane(__double2loint(qk)));
-            }
+            for (int k = 0; k < D; ++k)
+                q[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(qraw[k])),
+                                        __builtin_amdgcn_readfirstlane(__double2loint(qraw[k])));
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < PPT; ++j) {
@@ -514,6 +527,10 @@ ens_stream_kernel(StreamArgs p) {
             }
             const double wsum = wave_sum_dpp(acc);
             if (lane == 63) scratch[par][wv - 1] = wsum;
+        }
+        if (comm) {                                   // idle until barrier B: prepare the store and the next proposal
+            out_row = p.hist + ((size_t)(t + 1) * WT + w) * row + lane;
+            if (t2 < p.K) decode_next(item + 1, t2, s2);
         }
         if (service) {                                // under the compute waves' kernel sum: ring slot item+2, issue item+3
             if (lane < 4) rec_s[pslot & 3][lane] = pend;
@@ -534,7 +551,7 @@ ens_stream_kernel(StreamArgs p) {
             const double outv = (lane < p.d) ? (acc_flag ? qv : sv) : (acc_flag ? lp_new : lp_old);
             const unsigned long long outw = (lane <= p.d) ? (unsigned long long)__double_as_longlong(outv)
                                                           : (unsigned long long)acc_flag;
-            if (lane <= p.d + 1) st_sc1(p.hist + ((size_t)(t + 1) * WT + w) * row + lane, outw);
+            if (lane <= p.d + 1) st_sc1(out_row, outw);
         }
         t = t2; split = s2; bb = b2; ++item;
 #ifdef ALABI_STREAM_PROF
@@ -608,7 +625,8 @@ static int ens_stream_ppt(const alabi_ens* e) {
     const bool generic = e->gp->kf.type != 0;
     int max_db = 0;
     if (T == 512) max_db = (ppt == 1) ? (generic ? 12 : 16) : (ppt == 2) ? (generic ? 6 : 10) : 0;
-    else max_db = (ppt <= 2) ? 16 : (ppt == 3) ? (generic ? 10 : 12) : (ppt == 4) ? (generic ? 6 : 10) : 0;
+    else max_db = (ppt == 1) ? 16 : (ppt == 2) ? (generic ? 12 : 16) : (ppt == 3) ? (generic ? 8 : 12)
+                                                                      : (ppt == 4) ? (generic ? 6 : 10) : 0;
     return db <= max_db ? ppt : 0;
 }
 
