@@ -30,6 +30,7 @@
 //                     on this chip).
 // The per-step work at the headline size (W=256, N=2000, d=10) is 2 x 128 workgroups x
 // 2000 kernel evaluations: latency bound, not HBM bound (X and alpha, 176 KB, stay in L2).
+#include <cstdlib>
 #include "gp_device.hpp"
 
 namespace alabi {
@@ -662,6 +663,7 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
     a.Xt = gp->Xt; a.alpha = gp->alpha; a.chain = chain; a.chain_logp = chain_logp;
     a.n_accept = reinterpret_cast<unsigned long long*>(n_accept); a.run_state = e->run_state;
     a.K = K; a.W = e->W; a.n0 = n0; a.d = e->d; a.Npad = gp->Npad; a.thin_by = thin_by; a.spin_limit = 1 << 20;
+    if (const char* env = getenv("ALABI_ENS_SPIN_LIMIT")) { const int v = atoi(env); if (v > 0) a.spin_limit = v; }   // tests: force a time-out
     a.amp = exp(gp->log_amp); a.mean = gp->mean; a.kf = gp->kf;
     const int db = dim_bucket(e->d);
     // lanes x pairs-per-lane cover Npad/2 point pairs; the launch-per-half-step kernel's lane -> point map (and so its

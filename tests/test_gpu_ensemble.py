@@ -205,3 +205,25 @@ def test_stream_kernel_equals_launch_per_half_step(setup, monkeypatch):
         # and a second run continues identically
         a.run_mcmc(None, 50); b.run_mcmc(None, 50)
         assert np.array_equal(a.get_chain(), b.get_chain())
+
+
+def test_persistent_kernel_timeout_falls_back(monkeypatch):
+    """A hand-off that does not arrive within the spin limit makes every workgroup of the persistent kernel leave; the
+    sampler restores the state and repeats the run on the launch-per-half-step path with the identical chain."""
+    from alabi_amd import EnsembleSampler, HipGP
+    X, y, h = make_problem(150, 3, 11, log_wn=-9.0)
+    g = HipGP(3, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+    bounds = np.array([[-3.0, 3.0]] * 3)
+    p0 = np.random.RandomState(1).uniform(-2, 2, (16, 3))
+    monkeypatch.setenv("ALABI_ENS_STREAM", "0")
+    ref = EnsembleSampler(16, 3, g, y, bounds, seed=4); ref.run_mcmc(p0, 60)
+    monkeypatch.setenv("ALABI_ENS_STREAM", "1")
+    monkeypatch.setenv("ALABI_ENS_SPIN_LIMIT", "1")          # the second half step can never be ready after one poll
+    s = EnsembleSampler(16, 3, g, y, bounds, seed=4); s.run_mcmc(p0, 60)
+    assert getattr(s, "stream_fallbacks", 0) == 1 and s.last_path == "launch-per-half-step"
+    np.testing.assert_array_equal(s.get_chain(), ref.get_chain())
+    np.testing.assert_array_equal(s.get_log_prob(), ref.get_log_prob())
+    np.testing.assert_array_equal(s.acceptance_fraction, ref.acceptance_fraction)
+    monkeypatch.delenv("ALABI_ENS_SPIN_LIMIT")
+    s.run_mcmc(None, 40); ref.run_mcmc(None, 40)              # the sampler stays on the fallback path and keeps going
+    np.testing.assert_array_equal(s.get_chain(), ref.get_chain())
