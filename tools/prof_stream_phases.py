@@ -1,4 +1,4 @@
-"""Phase breakdown of the persistent ensemble kernel (needs a build with -DALABI_STREAM_PROF: see tools/README)."""
+"""Phase breakdown of the persistent ensemble kernel (needs a build with -DALABI_STREAM_PROF: see tools/README.md)."""
 import ctypes, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
