@@ -283,23 +283,26 @@ ws_produce_tile(const double* L_, const double* dinv_, int Npad, const double* V
     // the wait for the OLDER set is a constant vmcnt and the younger set stays in flight.
     f64x2 pa[2][8], pv[2][8];
     double pd[2];
+    // Thread t8 owns row t8 >> 2 of a 64 x 64 block and the 16-byte chunks (t8 & 3) + 4 i, i = 0..7, of that row: one base
+    // address per block, the eight loads and LDS writes differ by immediates (64 B apart; a wave covers 16 rows x 64 B).
+    const int prow = t8 >> 2, pch = t8 & 3;
 #define ALABI_WS_ISSUE(SET, KB, S)                                                                            \
     {                                                                                                         \
-        const ws_gcptr Lb_ = L + (size_t)((KB) * 64) * ld + (S) * 64;                                         \
-        const ws_gcptr2 Vj_ = (ws_gcptr2)(V + (size_t)(((S) < (KB) ? (S) : 0) * 64) * 64);                    \
+        const ws_gcptr2 Lb_ = (ws_gcptr2)(L + ((size_t)((KB) * 64 + prow)) * ld + (S) * 64) + pch;            \
+        const ws_gcptr2 Vj_ = (ws_gcptr2)(V + ((size_t)(((S) < (KB) ? (S) : 0) * 64 + prow)) * 64) + pch;     \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                       \
-            const int e = t8 + 256 * i, r = e >> 5, c2 = e & 31;                                              \
-            pa[SET][i] = *(ws_gcptr2)(Lb_ + (size_t)r * ld + 2 * c2);                                         \
-            pv[SET][i] = Vj_[e];                                                                              \
+            pa[SET][i] = Lb_[4 * i];                                                                          \
+            pv[SET][i] = Vj_[4 * i];                                                                          \
         }                                                                                                     \
         pd[SET] = dinv[(KB) * 64 + (t8 & 63)];                                                                \
     }
 #define ALABI_WS_TO_LDS(SET, BUF, WITH_V)                                                                     \
     {                                                                                                         \
+        f64x2* as_ = reinterpret_cast<f64x2*>(&ws_As[BUF][prow][0]) + pch;                                    \
+        f64x2* vs_ = reinterpret_cast<f64x2*>(&ws_Vs[BUF][prow][0]) + pch;                                    \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                       \
-            const int e = t8 + 256 * i, r = e >> 5, c2 = e & 31;                                              \
-            *reinterpret_cast<f64x2*>(&ws_As[BUF][r][2 * c2]) = pa[SET][i];                                   \
-            if (WITH_V) *reinterpret_cast<f64x2*>(&ws_Vs[BUF][r][2 * c2]) = pv[SET][i];                       \
+            as_[4 * i] = pa[SET][i];                                                                          \
+            if (WITH_V) vs_[4 * i] = pv[SET][i];                                                              \
         }                                                                                                     \
         if (t8 < 64) ws_dis[BUF][t8] = pd[SET];                                                               \
     }
