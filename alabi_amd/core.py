@@ -584,7 +584,8 @@ class SurrogateModel(object):
         """Next training point = arg-min of the acquisition function (core.py:1587-1667).
 
         obj_opt_method "scan" (default here): ``ncand`` uniform candidates in the scaled box are scored in
-        one batched HIP pass (predict mean+variance -> utility -> arg-min).  Any scipy method name keeps
+        one batched HIP pass (predict mean+variance -> utility -> arg-min), then ``refine`` zoom stages of
+        ``nrefine`` candidates each around the ``ntop`` best.  Any scipy method name keeps
         the reference's multistart local optimisation with one GP prediction per objective call."""
         t0 = time.time()
         y_best = float(np.max(self._y))
@@ -597,7 +598,30 @@ class SurrogateModel(object):
             lo = torch.as_tensor(self._bounds[:, 0], device=_dev())
             hi = torch.as_tensor(self._bounds[:, 1], device=_dev())
             cand = lo + (hi - lo) * torch.rand((ncand, self.ndim), dtype=torch.float64, device=_dev(), generator=gen)
-            _thetaN, _, idx = ut.utility_scan(self.gp, self._y, cand, self._bounds, algorithm=self.algorithm, y_best=y_best)
+            nref, nper, ntop = int(kw.get("refine", 3)), int(kw.get("nrefine", 16384)), int(kw.get("ntop", 32))
+            out = ut.utility_scan(self.gp, self._y, cand, self._bounds, algorithm=self.algorithm, y_best=y_best,
+                                  return_all=nref > 0)
+            _thetaN, u_best, idx = out[:3]
+            # Zoom stages (stand in for the reference's local optimiser, utility.py:1030-1163, at batched-scan cost):
+            # Gaussian clouds of shrinking width around the best candidates so far, scored in one pass each.
+            if idx >= 0 and nref > 0:
+                u_all = torch.where(torch.isfinite(out[3]), out[3], torch.full_like(out[3], float("inf")))
+                k = min(ntop, ncand)
+                centers = cand[torch.topk(-u_all, k).indices]
+                width = 0.08 * (hi - lo)
+                for _ in range(nref):
+                    rep = centers[torch.randint(0, centers.shape[0], (nper,), device=_dev(), generator=gen)]
+                    cloud = rep + width * torch.randn((nper, self.ndim), dtype=torch.float64, device=_dev(), generator=gen)
+                    cloud = torch.minimum(torch.maximum(cloud, lo + 1e-12 * (hi - lo)), hi - 1e-12 * (hi - lo))
+                    cloud[0] = torch.as_tensor(_thetaN, device=_dev())          # the incumbent can only be improved on
+                    o2 = ut.utility_scan(self.gp, self._y, cloud, self._bounds, algorithm=self.algorithm, y_best=y_best,
+                                         return_all=True)
+                    if o2[2] >= 0 and o2[1] <= u_best:
+                        _thetaN, u_best = o2[0], o2[1]
+                    u2 = torch.where(torch.isfinite(o2[3]), o2[3], torch.full_like(o2[3], float("inf")))
+                    centers = cloud[torch.topk(-u2, min(ntop, nper)).indices]
+                    width = 0.3 * width
+            self.last_acquisition_value = float(u_best) if idx >= 0 else np.nan
             if idx < 0:
                 _thetaN = np.nan
         else:
@@ -606,7 +630,7 @@ class SurrogateModel(object):
                 obj_fn = partial(self.utility, predict_gp=predict_gp, bounds=self._bounds, y_best=y_best)
             else:
                 obj_fn = partial(self.utility, predict_gp=predict_gp, bounds=self._bounds)
-            for k in ("ncand", "polish"):
+            for k in ("ncand", "polish", "refine", "nrefine", "ntop"):
                 kw.pop(k, None)
             _thetaN, _ = ut.minimize_objective(obj_fn, bounds=self._bounds, nopt=nopt, ps=self._prior_sampler,
                                                method=self.obj_opt_method, options=kw or None, grad_obj_fn=None)
