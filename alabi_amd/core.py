@@ -598,7 +598,7 @@ class SurrogateModel(object):
             lo = torch.as_tensor(self._bounds[:, 0], device=_dev())
             hi = torch.as_tensor(self._bounds[:, 1], device=_dev())
             cand = lo + (hi - lo) * torch.rand((ncand, self.ndim), dtype=torch.float64, device=_dev(), generator=gen)
-            nref, nper, ntop = int(kw.get("refine", 3)), int(kw.get("nrefine", 16384)), int(kw.get("ntop", 32))
+            nref, nper, ntop = int(kw.get("refine", 4)), int(kw.get("nrefine", 4096)), int(kw.get("ntop", 32))
             out = ut.utility_scan(self.gp, self._y, cand, self._bounds, algorithm=self.algorithm, y_best=y_best,
                                   return_all=nref > 0)
             _thetaN, u_best, idx = out[:3]

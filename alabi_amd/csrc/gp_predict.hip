@@ -274,14 +274,15 @@ __shared__ double ws_dis[2][64];
 // merges the live ranges of both roles and spills hundreds of VGPRs.  No store and no spill may sit in the stage loop: on
 // gfx950 loads and stores share one counter, and with both kinds pending the compiler can only wait for ALL of them
 // (vmcnt(0)), which would drain the stage that is meant to stay in flight.
+template <int TM>
 __device__ __attribute__((noinline)) void
 ws_produce_tile(const double* L_, const double* dinv_, int Npad, const double* V_) {
     const ws_gcptr L = (ws_gcptr)L_, dinv = (ws_gcptr)dinv_, V = (ws_gcptr)V_;
     const int t8 = threadIdx.x - 256;          // 256 producer threads: 8 + 8 loads per stage each
     const int nb = Npad / 64, ld = Npad, nstages = nb * (nb + 1) / 2;
-    // Two register sets; every stage issues exactly 8 + 8 + 1 loads (a diagonal stage loads a V block it does not use), so
+    // Two register sets; every stage issues exactly 8 + TM/8 + 1 loads (a diagonal stage loads a V block it does not use), so
     // the wait for the OLDER set is a constant vmcnt and the younger set stays in flight.
-    f64x2 pa[2][8], pv[2][8];
+    f64x2 pa[2][8], pv[2][TM / 8];
     double pd[2];
     // Thread t8 owns row t8 >> 2 of a 64 x 64 block and the 16-byte chunks (t8 & 3) + 4 i, i = 0..7, of that row: one base
     // address per block, the eight loads and LDS writes differ by immediates (64 B apart; a wave covers 16 rows x 64 B).
@@ -289,21 +290,17 @@ ws_produce_tile(const double* L_, const double* dinv_, int Npad, const double* V
 #define ALABI_WS_ISSUE(SET, KB, S)                                                                            \
     {                                                                                                         \
         const ws_gcptr2 Lb_ = (ws_gcptr2)(L + ((size_t)((KB) * 64 + prow)) * ld + (S) * 64) + pch;            \
-        const ws_gcptr2 Vj_ = (ws_gcptr2)(V + ((size_t)(((S) < (KB) ? (S) : 0) * 64 + prow)) * 64) + pch;     \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                       \
-            pa[SET][i] = Lb_[4 * i];                                                                          \
-            pv[SET][i] = Vj_[4 * i];                                                                          \
-        }                                                                                                     \
+        const ws_gcptr2 Vj_ = (ws_gcptr2)(V + ((size_t)(((S) < (KB) ? (S) : 0) * 64 + prow)) * TM) + pch;     \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) pa[SET][i] = Lb_[4 * i];                                \
+        _Pragma("unroll") for (int i = 0; i < TM / 8; ++i) pv[SET][i] = Vj_[4 * i];                           \
         pd[SET] = dinv[(KB) * 64 + (t8 & 63)];                                                                \
     }
 #define ALABI_WS_TO_LDS(SET, BUF, WITH_V)                                                                     \
     {                                                                                                         \
         f64x2* as_ = reinterpret_cast<f64x2*>(&ws_As[BUF][prow][0]) + pch;                                    \
         f64x2* vs_ = reinterpret_cast<f64x2*>(&ws_Vs[BUF][prow][0]) + pch;                                    \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                       \
-            as_[4 * i] = pa[SET][i];                                                                          \
-            if (WITH_V) vs_[4 * i] = pv[SET][i];                                                              \
-        }                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) as_[4 * i] = pa[SET][i];                                \
+        if (WITH_V) { _Pragma("unroll") for (int i = 0; i < TM / 8; ++i) vs_[4 * i] = pv[SET][i]; }           \
         if (t8 < 64) ws_dis[BUF][t8] = pd[SET];                                                               \
     }
 #define ALABI_WS_ADVANCE(KB, S) { if (++(S) > (KB)) { ++(KB); (S) = 0; } }
@@ -361,20 +358,26 @@ ws_produce_tile(const double* L_, const double* dinv_, int Npad, const double* V
 }
 
 // Consumer waves of one tile: returns this lane's share of |L^-1 k*|^2 (before the cross-lane fold).
+template <int TM>
 __device__ __attribute__((noinline)) double
 ws_consume_tile(int Npad, double* V_) {
+    constexpr int NT = TM / 16;            // MFMA column tiles per wave
+    constexpr int CPW = TM / 4;            // solve: columns per wave ...
+    constexpr int LPC = 64 / CPW;          // ... lanes per column (lane group g holds rows g, g + LPC, ...)
+    constexpr int RPL = 64 / LPC;          // ... rows per lane
     const ws_gptr V = (ws_gptr)V_;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
     const int lr = lane & 15, lk = lane >> 4;  // MFMA lane decomposition
+    const int cl = lane % CPW, g = lane / CPW;
     const int nb = Npad / 64;
     double ss = 0.0;
     __syncthreads();                   // stage 0 is in LDS
-    v4f64 acc[4];
+    v4f64 acc[NT];
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[n][i] = V[(size_t)(16 * w + lk + 4 * i) * 64 + 16 * n + lr];
+        for (int i = 0; i < 4; ++i) acc[n][i] = V[(size_t)(16 * w + lk + 4 * i) * TM + 16 * n + lr];
     int b = 0;
     for (int kb = 0; kb < nb; ++kb)
         for (int sj = 0; sj <= kb; ++sj, ++b) {
@@ -385,7 +388,7 @@ ws_consume_tile(int Npad, double* V_) {
                 for (int ks = 0; ks < 16; ++ks) {
                     const double a = -ws_As[buf][16 * w + lr][4 * ks + lk];
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) {
+                    for (int n = 0; n < NT; ++n) {
                         const double bb = ws_Vs[buf][4 * ks + lk][16 * n + lr];
                         if (!ALABI_PV_NO_MFMA) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[n], 0, 0, 0);
                     }
@@ -393,39 +396,39 @@ ws_consume_tile(int Npad, double* V_) {
                 continue;
             }
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ws_Vs[buf][16 * w + lk + 4 * i][16 * n + lr] = acc[n][i];
-            if (kb + 1 < nb) {             // next block row's accumulator seed (K* rows parked by the producers)
+            if (kb + 1 < nb) {             // next block row's accumulator seed (the K* pre-pass left it in the workspace)
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
+                for (int n = 0; n < NT; ++n)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        acc[n][i] = V[(size_t)((kb + 1) * 64 + 16 * w + lk + 4 * i) * 64 + 16 * n + lr];
+                        acc[n][i] = V[(size_t)((kb + 1) * 64 + 16 * w + lk + 4 * i) * TM + 16 * n + lr];
             }
             __syncthreads();
-            // diagonal solve: wave w owns columns 16w..16w+15; lane (col lr, group lk) holds rows == lk (mod 4)
-            const int col = 16 * w + lr;
-            double v[16];
+            // diagonal solve: wave w owns columns CPW w .. CPW w + CPW - 1; lane (col cl, group g) holds rows == g (mod LPC)
+            const int col = CPW * w + cl;
+            double v[RPL];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) v[t] = ws_Vs[buf][4 * t + lk][col];
+            for (int t = 0; t < RPL; ++t) v[t] = ws_Vs[buf][LPC * t + g][col];
 #pragma unroll
             for (int r = 0; r < 64; ++r) {
-                const int owner = r & 3, t = r >> 2;
+                const int owner = r % LPC, t = r / LPC;
                 double x = v[t] * ws_dis[buf][r];
-                x = __shfl(x, lr + 16 * owner, 64);
-                // rows of the pivot's own group of four: lanes below the pivot are done (select, no branch: straight-line
-                // code); every later group takes the update unconditionally
-                const double a_own = ws_As[buf][4 * t + lk][r];
-                v[t] = (lk == owner) ? x : ((lk > owner) ? fma(-a_own, x, v[t]) : v[t]);
+                x = __shfl(x, cl + CPW * owner, 64);
+                // rows of the pivot's own group: lanes below the pivot are done (select, no branch: straight-line code);
+                // every later group takes the update unconditionally
+                const double a_own = ws_As[buf][LPC * t + g][r];
+                v[t] = (g == owner) ? x : ((g > owner) ? fma(-a_own, x, v[t]) : v[t]);
 #pragma unroll
-                for (int t2 = t + 1; t2 < 16; ++t2) v[t2] = fma(-ws_As[buf][4 * t2 + lk][r], x, v[t2]);
+                for (int t2 = t + 1; t2 < RPL; ++t2) v[t2] = fma(-ws_As[buf][LPC * t2 + g][r], x, v[t2]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                V[(size_t)(kb * 64 + 4 * t + lk) * 64 + col] = v[t];
-                if (kb == 0) ws_Vs[nbuf][4 * t + lk][col] = v[t];   // stage (1, 0) follows at once: hand V_0 over in LDS
+            for (int t = 0; t < RPL; ++t) {
+                V[(size_t)(kb * 64 + LPC * t + g) * TM + col] = v[t];
+                if (kb == 0) ws_Vs[nbuf][LPC * t + g][col] = v[t];   // stage (1, 0) follows at once: hand V_0 over in LDS
                 ss = fma(v[t], v[t], ss);
             }
         }
@@ -439,13 +442,14 @@ template <int D, bool GENERIC>
 __global__ void __launch_bounds__(256)
 predict_kstar_tile_kernel(const double* __restrict__ Xt, const double* __restrict__ alpha, int N, int Npad,
                           const double* __restrict__ Xs, int d, long long M, DimVec inv_len, double amp, double mean,
-                          KernelFn kf, double* __restrict__ ws, double* __restrict__ mu) {
+                          KernelFn kf, double* __restrict__ ws, double* __restrict__ mu, int TM) {
     __shared__ double xt[D][256];
     __shared__ double al[256];
     __shared__ double part[4][64];
     const int tid = threadIdx.x, c = tid & 63, w = tid >> 6;
     const long long m = (long long)blockIdx.x * 64 + c;
-    double* V = ws + (size_t)blockIdx.x * Npad * 64;
+    // 64 queries per workgroup = 64 / TM variance tiles of TM queries, each [Npad][TM] in the workspace
+    double* V = ws + ((size_t)blockIdx.x * (64 / TM) + c / TM) * Npad * TM + (c % TM);
     double q[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) q[k] = (m < M && k < d) ? Xs[m * d + k] * inv_len.v[k] : 0.0;
@@ -469,7 +473,7 @@ predict_kstar_tile_kernel(const double* __restrict__ Xt, const double* __restric
             }
             const double kv = (n0 + nn < N) ? amp * radial<GENERIC>(r2, kf) : 0.0;
             acc = fma(kv, al[nn], acc);
-            V[(size_t)(n0 + nn) * 64 + c] = kv;
+            V[(size_t)(n0 + nn) * TM] = kv;
         }
     }
     part[w][c] = acc;
@@ -477,25 +481,28 @@ predict_kstar_tile_kernel(const double* __restrict__ Xt, const double* __restric
     if (tid < 64 && m < M) mu[m] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + mean;
 }
 
-// One workgroup per CU walks over the tiles; tile t owns workspace rows ws[t] (K* seeds in, V out).
+// One workgroup per CU walks over the tiles of TM queries; tile t owns workspace rows ws[t] (K* seeds in, V out).
+// TM = 64 for throughput; TM = 16 when there are too few queries to give every CU a 64-wide tile (a tile's latency is
+// its 528 dependent stages at N = 2000, and a 16-wide stage is four times less MFMA work).
+template <int TM>
 __global__ void __launch_bounds__(512)
 predict_var_ws_kernel(const double* __restrict__ L, const double* __restrict__ dinv, int Npad, long long M, double amp,
                       double* __restrict__ ws, double* __restrict__ var) {
+    constexpr int CPW = TM / 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, lk = lane >> 4;
-    const long long ntiles = (M + 63) / 64;
+    const long long ntiles = (M + TM - 1) / TM;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        double* V = ws + (size_t)tile * Npad * 64;
+        double* V = ws + (size_t)tile * Npad * TM;
         __syncthreads();                       // the previous tile is completely finished with the LDS stages
         if (wv >= 4) {
-            ws_produce_tile(L, dinv, Npad, V);
+            ws_produce_tile<TM>(L, dinv, Npad, V);
         } else {
-            double ss = ws_consume_tile(Npad, V);
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
-            const long long mc = tile * 64 + 16 * wv + lr;
-            if (lk == 0 && mc < M) var[mc] = amp - ss;
+            double ss = ws_consume_tile<TM>(Npad, V);   // lane (column lane % CPW, row group lane / CPW) of wave wv's columns
+#pragma unroll
+            for (int off = CPW; off < 64; off <<= 1) ss += __shfl_xor(ss, off, 64);
+            const long long mc = tile * TM + CPW * wv + (lane % CPW);
+            if (lane < CPW && mc < M) var[mc] = amp - ss;
         }
     }
 }
@@ -532,8 +539,10 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
         int dev = 0, n_cu = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        // 16-wide tiles when 64-wide ones cannot give every CU a tile
+        const int TM = (M <= 16LL * n_cu) ? 16 : 64;
         // tiles per chunk: a whole number of rounds over the CUs within ~2 GiB of workspace (at least one round)
-        long long chunk_tiles = (2LL << 30) / ((long long)gp->Npad * 64 * 8);
+        long long chunk_tiles = (2LL << 30) / ((long long)gp->Npad * 64 * 8);     // in 64-query units
         chunk_tiles = chunk_tiles / n_cu * n_cu;
         if (chunk_tiles < n_cu) chunk_tiles = n_cu;
         if (const char* env = getenv("ALABI_PV_CHUNK_TILES")) { const long long v = atoll(env); if (v > 0) chunk_tiles = v; }   // tests
@@ -551,13 +560,18 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
         }
         for (long long m0 = 0; m0 < M; m0 += chunk) {
             const long long mc = (M - m0 < chunk) ? M - m0 : chunk;
-            const long long tiles_c = (mc + 63) / 64;
+            const long long groups = (mc + 63) / 64;                               // K* workgroups (64 queries each)
             ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_kstar_tile_kernel<D, GENERIC>),
-                dim3((unsigned)tiles_c), dim3(256), 0, s, gp->Xt, gp->alpha, gp->N, gp->Npad, Xs + m0 * gp->d, gp->d, mc,
-                gp->inv_len, amp, gp->mean, gp->kf, gp->ws, mu + m0)));
+                dim3((unsigned)groups), dim3(256), 0, s, gp->Xt, gp->alpha, gp->N, gp->Npad, Xs + m0 * gp->d, gp->d, mc,
+                gp->inv_len, amp, gp->mean, gp->kf, gp->ws, mu + m0, TM)));
+            const long long tiles_c = (mc + TM - 1) / TM;
             const int grid_c = (int)(tiles_c < n_cu ? tiles_c : n_cu);
-            hipLaunchKernelGGL(predict_var_ws_kernel, dim3(grid_c), dim3(512), 0, s, gp->L, gp->dinv, gp->Npad, mc, amp, gp->ws,
-                               var + m0);
+            if (TM == 16)
+                hipLaunchKernelGGL(predict_var_ws_kernel<16>, dim3(grid_c), dim3(512), 0, s, gp->L, gp->dinv, gp->Npad, mc, amp,
+                                   gp->ws, var + m0);
+            else
+                hipLaunchKernelGGL(predict_var_ws_kernel<64>, dim3(grid_c), dim3(512), 0, s, gp->L, gp->dinv, gp->Npad, mc, amp,
+                                   gp->ws, var + m0);
         }
         ALABI_LAUNCH_CHECK();
         return ALABI_OK;

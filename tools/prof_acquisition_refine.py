@@ -10,7 +10,7 @@ sm.init_gp(hyperopt_method="ml", gp_nopt=1, optimizer_kwargs={"maxiter": 3})
 for algo in ("agp", "bape"):
   sm.active_train(niter=1, algorithm=algo, gp_opt_freq=1000, optimizer_kwargs={"ncand": 4096, "refine": 0})
   print(algo)
-  for refine, ncand, nper in ((0, 65536, 0), (0, 1000000, 0), (2, 65536, 8192), (3, 65536, 8192), (2, 65536, 16384), (3, 65536, 16384)):
+  for refine, ncand, nper in ((0, 65536, 0), (0, 1000000, 0), (3, 65536, 16384), (3, 65536, 4096), (4, 65536, 4096), (5, 65536, 4096), (4, 16384, 4096)):
         vals = []; t0 = time.perf_counter()
         for rep in range(5):
             sm.random_state = rep
