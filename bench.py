@@ -154,6 +154,9 @@ def main():
                          "headline configuration: ONE 256-walker ensemble per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the predict / Cholesky side measurements")
+    ap.add_argument("--shard-extra", action="store_true",
+                    help="N > 1: also time ONE ensemble of 256*N walkers sharded over the ranks (all-gather per half step); "
+                         "opt-in so that an untested collective path can never cost the headline line")
     args = ap.parse_args()
 
     import torch
@@ -258,9 +261,9 @@ def main():
 
     # Secondary measurement on N > 1 GPUs (every rank takes part): ONE ensemble of 256*N walkers sharded over the ranks
     # with an RCCL all-gather of the updated half after every half step (alabi_amd/dist.py).  Reported next to the
-    # replica number; never the headline value.
+    # replica number; never the headline value.  Opt-in (--shard-extra).
     shard_info = None
-    if world > 1 and not shard and not args.no_extras:
+    if world > 1 and not shard and args.shard_extra:
         try:
             from alabi_amd.dist import HipBackend, ShardedEnsemble
             Wtot = W * world
