@@ -97,6 +97,8 @@ int alabi_gp_destroy(alabi_gp* gp) {
     if (gp->info) (void)hipFree(gp->info);
     if (gp->ws) (void)hipFree(gp->ws);
     if (gp->scan) (void)hipFree(gp->scan);
+    if (gp->winv) (void)hipFree(gp->winv);
+    if (gp->small) (void)hipFree(gp->small);
     delete gp;
     return ALABI_OK;
 }
@@ -135,6 +137,7 @@ int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream) {
     gp->last_pivot = info;
     if (info != 0) return ALABI_NOT_POSITIVE_DEFINITE;
     gp->computed = true;
+    gp->factor_gen++;
     return ALABI_OK;
 }
 
@@ -166,7 +169,14 @@ int alabi_gp_predict(alabi_gp* gp, const double* Xs, long long M, double* mu, do
     if (!gp->computed || !gp->has_alpha) return ALABI_NOT_COMPUTED;
     if (M == 0) return ALABI_OK;
     hipStream_t s = as_stream(stream);
-    if (var) return launch_predict_var(gp, Xs, M, mu, var, s);
+    if (var) {
+        // at most 16 queries: one multiply with the cached L^-1 spread over the block rows instead of 500+ dependent
+        // substitution stages (the path of per-point objective calls: utility.py:1030-1163, core.py:1441)
+        const char* env = getenv("ALABI_PV_SMALL");
+        if (M <= 16 && gp->Npad >= 256 && gp->d <= 16 && !(env && env[0] == '0'))
+            return launch_predict_var_small(gp, Xs, (int)M, mu, var, s);
+        return launch_predict_var(gp, Xs, M, mu, var, s);
+    }
     return launch_predict_mean(gp, Xs, M, mu, s);
 }
 

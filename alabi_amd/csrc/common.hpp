@@ -77,6 +77,12 @@ struct alabi_gp {
     size_t ws_bytes = 0;
     double* scan = nullptr;   // utility-scan scratch (partials)
     size_t scan_bytes = 0;
+    double* winv = nullptr;   // L^-1, tile-major, for variance requests of at most 16 queries (built lazily per factor)
+    size_t winv_bytes = 0;
+    long long factor_gen = 0; // bumped by every successful compute
+    long long winv_gen = -1;  // factor_gen the cached L^-1 belongs to
+    double* small = nullptr;  // [Npad / 64][16] partial sums of the small-batch variance kernel
+    size_t small_bytes = 0;
 };
 
 namespace alabi {
@@ -138,6 +144,8 @@ int launch_reductions(alabi_gp* gp, hipStream_t s);
 // gp_predict.hip
 int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu, hipStream_t s);
 int launch_factor_inverse(alabi_gp* gp, hipStream_t s);
+int launch_factor_inverse_into(alabi_gp* gp, double* dst, hipStream_t s);
+int launch_predict_var_small(alabi_gp* gp, const double* Xs, int M, double* mu, double* var, hipStream_t s);
 int launch_grad_log_likelihood(alabi_gp* gp, double* grad_dev, hipStream_t s);
 int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var,
                        hipStream_t s);

@@ -548,14 +548,22 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
         if (const char* env = getenv("ALABI_PV_CHUNK_TILES")) { const long long v = atoll(env); if (v > 0) chunk_tiles = v; }   // tests
         long long chunk = chunk_tiles * 64;                                       // queries per chunk
         if (chunk > M) chunk = (M + 63) / 64 * 64;
-        const size_t need = (size_t)(chunk / 64) * gp->Npad * 64 * sizeof(double);
+        size_t need = (size_t)(chunk / 64) * gp->Npad * 64 * sizeof(double);
         if (need > gp->ws_bytes) {
             if (gp->ws) {
                 ALABI_HIP_CHECK(hipStreamSynchronize(s));
                 ALABI_HIP_CHECK(hipFree(gp->ws));
                 gp->ws = nullptr; gp->ws_bytes = 0;
             }
-            ALABI_HIP_CHECK(hipMalloc(&gp->ws, need));
+            // short of memory: halve the chunk down to one round over the CUs before giving up
+            while (hipMalloc(&gp->ws, need) != hipSuccess) {
+                (void)hipGetLastError();
+                gp->ws = nullptr;
+                if (chunk <= 64LL * n_cu) return ALABI_HIP_ERROR;
+                chunk = (chunk / 2 + 63) / 64 * 64;
+                if (chunk < 64LL * n_cu) chunk = 64LL * n_cu;
+                need = (size_t)(chunk / 64) * gp->Npad * 64 * sizeof(double);
+            }
             gp->ws_bytes = need;
         }
         for (long long m0 = 0; m0 < M; m0 += chunk) {
@@ -596,9 +604,19 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
     return ALABI_OK;
 }
 
-// L^-1 into the workspace, tile-major: ws[t] = L^-1[:, 64t:64t+64] as [Npad][64] (rows above block t unspecified).
-int launch_factor_inverse(alabi_gp* gp, hipStream_t s) {
+// L^-1 tile-major into dst: dst[t] = L^-1[:, 64t:64t+64] as [Npad][64] (rows above block t unspecified, the upper part
+// of the diagonal block exact zeros).
+int launch_factor_inverse_into(alabi_gp* gp, double* dst, hipStream_t s) {
     const int nb = gp->Npad / 64;
+    hipLaunchKernelGGL((predict_var_kernel<1, true>), dim3(nb), dim3(256), 0, s, gp->L, gp->dinv, gp->Xt, gp->alpha, gp->N,
+                       gp->Npad, (const double*)nullptr, gp->d, (long long)gp->Npad, gp->inv_len, 1.0, 0.0, dst,
+                       (double*)nullptr, (double*)nullptr, 0, gp->kf);
+    ALABI_LAUNCH_CHECK();
+    return ALABI_OK;
+}
+
+// ... into the variance workspace (the gradient's use)
+int launch_factor_inverse(alabi_gp* gp, hipStream_t s) {
     const size_t need = (size_t)gp->Npad * gp->Npad * sizeof(double);
     if (need > gp->ws_bytes) {
         if (gp->ws) {
@@ -609,9 +627,109 @@ int launch_factor_inverse(alabi_gp* gp, hipStream_t s) {
         ALABI_HIP_CHECK(hipMalloc(&gp->ws, need));
         gp->ws_bytes = need;
     }
-    hipLaunchKernelGGL((predict_var_kernel<1, true>), dim3(nb), dim3(256), 0, s, gp->L, gp->dinv, gp->Xt, gp->alpha, gp->N,
-                       gp->Npad, (const double*)nullptr, gp->d, (long long)gp->Npad, gp->inv_len, 1.0, 0.0, gp->ws,
-                       (double*)nullptr, (double*)nullptr, 0, gp->kf);
+    return launch_factor_inverse_into(gp, gp->ws, s);
+}
+
+// Variance of at most 16 queries from the cached W = L^-1: v = W k*, var = amp - |v|^2.  One workgroup per block row kb
+// forms v_kb = sum_{j <= kb} W[kb,j] K*_j on the matrix cores (the K* blocks are re-evaluated per workgroup: 64 x 16
+// kernel values per block) and leaves its 16 partial sums of squares; a second tiny kernel adds them in block order.
+template <int D, bool GENERIC>
+__global__ void __launch_bounds__(256)
+predict_var_small_kernel(const double* __restrict__ W, const double* __restrict__ Xt, int N, int Npad,
+                         const double* __restrict__ Xs, int d, int M, DimVec inv_len, double amp, KernelFn kf,
+                         double* __restrict__ partial) {
+    __shared__ double Wt[64][66];
+    __shared__ double Ks[64][18];
+    __shared__ double qs[16][D];
+    __shared__ double red[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int kb = blockIdx.x;
+    for (int e = tid; e < 16 * D; e += 256) {
+        const int m = e / D, k = e % D;
+        qs[m][k] = (m < M && k < d) ? Xs[(size_t)m * d + k] * inv_len.v[k] : 0.0;
+    }
+    v4f64 acc = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j <= kb; ++j) {
+        __syncthreads();                                   // the previous block's MFMAs are done with Wt / Ks (and qs is set)
+        const double* Wb = W + (size_t)j * Npad * 64 + (size_t)(kb * 64) * 64;   // rows of block kb inside column tile j
+        for (int e = tid; e < 2048; e += 256) {
+            const int r = e >> 5, c2 = e & 31;
+            *reinterpret_cast<f64x2*>(&Wt[r][2 * c2]) = reinterpret_cast<const f64x2*>(Wb)[e];
+        }
+        {   // K*_j: thread (point p = lane, queries 4w .. 4w+3)
+            const int n = j * 64 + lane;
+            double x[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) x[k] = Xt[(size_t)k * Npad + n];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = 4 * w + i;
+                double r2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) { const double df = x[k] - qs[m][k]; r2 = fma(df, df, r2); }
+                Ks[lane][m] = (n < N && m < M) ? amp * radial<GENERIC>(r2, kf) : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[16 * w + lr][4 * ks + lk], Ks[4 * ks + lk][lr], acc, 0, 0, 0);
+    }
+    // acc[i] = v[row 16w + lk + 4i][query lr]: squares summed over the rows of this wave, then over the waves
+    double ss = fma(acc[0], acc[0], fma(acc[1], acc[1], fma(acc[2], acc[2], acc[3] * acc[3])));
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (lane < 16) red[w][lane] = ss;
+    __syncthreads();
+    if (tid < 16) partial[(size_t)kb * 16 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+__global__ void __launch_bounds__(64)
+predict_var_small_final_kernel(const double* __restrict__ partial, int nb, int M, double amp, double* __restrict__ var) {
+    const int m = threadIdx.x;
+    if (m >= M) return;
+    double s = 0.0;
+    for (int kb = 0; kb < nb; ++kb) s += partial[(size_t)kb * 16 + m];
+    var[m] = amp - s;
+}
+
+int launch_predict_var_small(alabi_gp* gp, const double* Xs, int M, double* mu, double* var, hipStream_t s) {
+    const int nb = gp->Npad / 64, db = dim_bucket(gp->d);
+    const size_t need = (size_t)gp->Npad * gp->Npad * sizeof(double);
+    if (need > gp->winv_bytes) {
+        if (gp->winv) {
+            ALABI_HIP_CHECK(hipStreamSynchronize(s));
+            ALABI_HIP_CHECK(hipFree(gp->winv));
+            gp->winv = nullptr; gp->winv_bytes = 0;
+        }
+        if (hipMalloc(&gp->winv, need) != hipSuccess) {     // no room for the cache: the substitution kernel does it
+            (void)hipGetLastError();
+            gp->winv = nullptr;
+            return launch_predict_var(gp, Xs, M, mu, var, s);
+        }
+        gp->winv_bytes = need;
+        gp->winv_gen = -1;
+    }
+    if (gp->small_bytes < (size_t)nb * 16 * sizeof(double)) {
+        if (gp->small) {
+            ALABI_HIP_CHECK(hipStreamSynchronize(s));
+            ALABI_HIP_CHECK(hipFree(gp->small));
+            gp->small = nullptr; gp->small_bytes = 0;
+        }
+        ALABI_HIP_CHECK(hipMalloc(&gp->small, (size_t)nb * 16 * sizeof(double)));
+        gp->small_bytes = (size_t)nb * 16 * sizeof(double);
+    }
+    int st;
+    if (gp->winv_gen != gp->factor_gen) {
+        if ((st = launch_factor_inverse_into(gp, gp->winv, s)) != ALABI_OK) return st;
+        gp->winv_gen = gp->factor_gen;
+    }
+    if ((st = launch_predict_mean(gp, Xs, M, mu, s)) != ALABI_OK) return st;
+    const double amp = exp(gp->log_amp);
+    ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_var_small_kernel<D, GENERIC>), dim3(nb),
+        dim3(256), 0, s, gp->winv, gp->Xt, gp->N, gp->Npad, Xs, gp->d, M, gp->inv_len, amp, gp->kf, gp->small)));
+    hipLaunchKernelGGL(predict_var_small_final_kernel, dim3(1), dim3(64), 0, s, gp->small, nb, M, amp, var);
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

@@ -318,3 +318,34 @@ def test_predict_variance_paths_agree(monkeypatch):
     mu_o, var_o = o2.predict(y2, Xs2, return_var=True)
     assert np.max(np.abs(mu2 - mu_o) / (np.abs(mu_o) + 1)) <= 1e-9
     assert np.max(np.abs(var2 - var_o)) <= 1e-7 * np.exp(h2["log_amp"])
+
+
+@pytest.mark.parametrize("N,d", [(300, 4), (1000, 10), (257, 1)])
+def test_small_batch_variance_path(N, d, monkeypatch):
+    """At most 16 queries take the cached-L^-1 path (one multiply spread over the block rows); it must agree with the oracle
+    and with the substitution kernel, survive a refit (the cache follows the factor) and a different training-set size."""
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    X, y, h = make_problem(N, d, 40 + N, log_wn=-8.0)
+    amp = np.exp(h["log_amp"])
+    g = HipGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+    o = OracleGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X)
+    rs = np.random.RandomState(N)
+    for M in (1, 5, 16):
+        Xs = rs.uniform(-3.1, 3.1, (M, d))
+        mu, var = g.predict(y, Xs, return_var=True)
+        mu_o, var_o = o.predict(y, Xs, return_var=True)
+        assert np.max(np.abs(mu - mu_o) / (np.abs(mu_o) + 1)) <= 1e-9
+        assert np.max(np.abs(var - var_o)) <= 1e-7 * amp
+        monkeypatch.setenv("ALABI_PV_SMALL", "0")
+        mu_s, var_s = g.predict(y, Xs, return_var=True)
+        monkeypatch.delenv("ALABI_PV_SMALL")
+        assert np.max(np.abs(var - var_s)) <= 1e-8 * amp and np.max(np.abs(mu - mu_s)) <= 1e-9 * (np.max(np.abs(mu_s)) + 1)
+    # refit with other hyper-parameters and fewer points: the cached inverse must be rebuilt
+    p = g.get_parameter_vector(); p[-1] += 0.3
+    g.set_parameter_vector(p); o.set_parameter_vector(p)
+    g.compute(X[: N - 70]); o.compute(X[: N - 70])
+    Xs = rs.uniform(-3.1, 3.1, (7, d))
+    mu, var = g.predict(y[: N - 70], Xs, return_var=True)
+    mu_o, var_o = o.predict(y[: N - 70], Xs, return_var=True)
+    assert np.max(np.abs(var - var_o)) <= 1e-7 * amp and np.max(np.abs(mu - mu_o) / (np.abs(mu_o) + 1)) <= 1e-9
