@@ -507,6 +507,167 @@ predict_var_ws_kernel(const double* __restrict__ L, const double* __restrict__ d
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variance as a plain product with the cached W = L^-1:  var = amp - colnorm^2(W K*^T).  Same producer / consumer
+// pipeline and the same stage sequence (kb, s), s <= kb, as predict_var_ws_kernel, but a stage is now
+// acc += W[kb,s] K*_s with NO dependency between stages: nothing waits for a V block, there is no diagonal solve and no
+// mid-stage barrier, and the block rows of one query tile can be split over several workgroups (`parts`) when there are
+// fewer tiles than CUs.  K* comes from the pre-pass (never overwritten here).  Agrees with the substitution kernels to
+// ~1e-14 amp at nugget e^-12 (tools/prof_small_batch.py).
+__device__ inline void wg_row_range(int nb, int part, int parts, int& r0, int& r1) {
+    // contiguous block rows with about the same number of stages: rows [r0, r1), stages of row r = r + 1
+    const long long S = (long long)nb * (nb + 1) / 2;
+    auto bound = [&](int p) {
+        if (p <= 0) return 0;
+        if (p >= parts) return nb;
+        const long long target = S * p / parts;
+        int r = (int)((sqrt(8.0 * (double)target + 1.0) - 1.0) * 0.5);
+        while ((long long)r * (r + 1) / 2 < target) ++r;
+        while (r > 0 && (long long)(r - 1) * r / 2 >= target) --r;
+        return r < nb ? r : nb;
+    };
+    r0 = bound(part); r1 = bound(part + 1);
+}
+
+__device__ __attribute__((noinline)) void
+wg_produce_tile(const double* W_, const double* K_, int Npad, int r0, int r1) {
+    const ws_gcptr W = (ws_gcptr)W_, Kst = (ws_gcptr)K_;
+    const int t8 = threadIdx.x - 256;          // 256 producer threads: 8 + 8 loads per stage each
+    const int prow = t8 >> 2, pch = t8 & 3;
+    const long long nst = (long long)r1 * (r1 + 1) / 2 - (long long)r0 * (r0 + 1) / 2;
+    if (nst <= 0) return;
+    f64x2 pa[2][8], pv[2][8];
+#define ALABI_WG_ISSUE(SET, KB, S)                                                                            \
+    {                                                                                                         \
+        const ws_gcptr2 Wb_ = (ws_gcptr2)(W + (size_t)(S) * Npad * 64 + ((size_t)((KB) * 64 + prow)) * 64) + pch; \
+        const ws_gcptr2 Kb_ = (ws_gcptr2)(Kst + ((size_t)((S) * 64 + prow)) * 64) + pch;                      \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) { pa[SET][i] = Wb_[4 * i]; pv[SET][i] = Kb_[4 * i]; }   \
+    }
+#define ALABI_WG_TO_LDS(SET, BUF)                                                                             \
+    {                                                                                                         \
+        f64x2* as_ = reinterpret_cast<f64x2*>(&ws_As[BUF][prow][0]) + pch;                                    \
+        f64x2* vs_ = reinterpret_cast<f64x2*>(&ws_Vs[BUF][prow][0]) + pch;                                    \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) { as_[4 * i] = pa[SET][i]; vs_[4 * i] = pv[SET][i]; }   \
+    }
+#define ALABI_WG_ADVANCE(KB, S) { if (++(S) > (KB)) { ++(KB); (S) = 0; } }
+    // stage b + 1 sits in set (b + 1) & 1; (k3, s3) is the next stage to issue, clamped to the last one
+    int k3 = r0, s3 = 0;
+    const int klast = r1 - 1;
+    ALABI_WG_ISSUE(0, k3, s3)                  // stage 0
+    if (k3 < klast || s3 < k3) ALABI_WG_ADVANCE(k3, s3)
+    ALABI_WG_ISSUE(1, k3, s3)                  // stage 1
+    ALABI_WG_TO_LDS(0, 0)
+    if (k3 < klast || s3 < k3) ALABI_WG_ADVANCE(k3, s3)
+    ALABI_WG_ISSUE(0, k3, s3)                  // stage 2
+    __syncthreads();                           // stage 0 is in LDS
+#define ALABI_WG_STAGE(NSET)                                                                                  \
+    {                                                                                                         \
+        __syncthreads();               /* stage b is in LDS buffer b & 1; the other buffer is free */         \
+        ALABI_WG_TO_LDS(NSET, (int)((b & 1) ^ 1))                                                             \
+        if (k3 < klast || s3 < k3) ALABI_WG_ADVANCE(k3, s3)                                                   \
+        ALABI_WG_ISSUE(NSET, k3, s3)                                                                          \
+        ++b;                                                                                                  \
+    }
+    long long b = 0;
+    // the consumers run one barrier per stage after the first; stage 0 needs none here beyond the one above
+    if (nst > 1) {
+        // iteration for stage b writes stage b + 1: executed for b = 0 .. nst - 2, preceded by that stage's barrier
+        // (stage 0's barrier is the __syncthreads above, so the first iteration skips it)
+        ALABI_WG_TO_LDS(1, 1)
+        if (k3 < klast || s3 < k3) ALABI_WG_ADVANCE(k3, s3)
+        ALABI_WG_ISSUE(1, k3, s3)
+        b = 1;
+        while (b < nst - 1) {
+            ALABI_WG_STAGE(0)
+            if (b >= nst - 1) break;
+            ALABI_WG_STAGE(1)
+        }
+        __syncthreads();                       // the barrier of the last stage
+    }
+#undef ALABI_WG_STAGE
+#undef ALABI_WG_ISSUE
+#undef ALABI_WG_TO_LDS
+#undef ALABI_WG_ADVANCE
+}
+
+// Consumer waves: returns this lane's partial sums of squares for its four columns 16 n + lr (rows 16w + lk + 4i).
+__device__ __attribute__((noinline)) v4f64
+wg_consume_tile(int r0, int r1) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
+    const int lr = lane & 15, lk = lane >> 4;
+    v4f64 ss = v4f64{0.0, 0.0, 0.0, 0.0};
+    if (r1 <= r0) return ss;
+    __syncthreads();                           // stage 0 is in LDS
+    v4f64 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = v4f64{0.0, 0.0, 0.0, 0.0};
+    long long b = 0;
+    for (int kb = r0; kb < r1; ++kb)
+        for (int sj = 0; sj <= kb; ++sj, ++b) {
+            const int buf = (int)(b & 1);
+            if (b > 0) __syncthreads();        // stage b is in LDS buffer buf
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const double a = ws_As[buf][16 * w + lr][4 * ks + lk];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const double bb = ws_Vs[buf][4 * ks + lk][16 * n + lr];
+                    acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[n], 0, 0, 0);
+                }
+            }
+            if (sj == kb) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ss[n] = fma(acc[n][i], acc[n][i], ss[n]);
+                    acc[n] = v4f64{0.0, 0.0, 0.0, 0.0};
+                }
+            }
+        }
+    return ss;
+}
+
+// grid = (tiles in flight, parts); partial[(tile * parts + part) * 64 + column]
+__global__ void __launch_bounds__(512)
+predict_var_w_kernel(const double* __restrict__ W, const double* __restrict__ Kst, int Npad, long long ntiles, int parts,
+                     double* __restrict__ partial) {
+    __shared__ double red[4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const int nb = Npad / 64, part = blockIdx.y;
+    int r0, r1;
+    wg_row_range(nb, part, parts, r0, r1);
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const double* K = Kst + (size_t)tile * Npad * 64;
+        __syncthreads();                       // the previous tile is completely finished with the LDS stages
+        if (wv >= 4) {
+            wg_produce_tile(W, K, Npad, r0, r1);
+        } else {
+            v4f64 ss = wg_consume_tile(r0, r1);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {      // over the row groups lk, then over the four waves (rows 16w ..)
+                ss[n] += __shfl_xor(ss[n], 16, 64);
+                ss[n] += __shfl_xor(ss[n], 32, 64);
+                if (lk == 0) red[wv][16 * n + lr] = ss[n];
+            }
+        }
+        __syncthreads();
+        if (tid < 64) partial[((size_t)tile * parts + part) * 64 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+predict_var_w_final_kernel(const double* __restrict__ partial, int parts, long long M, double amp, double* __restrict__ var) {
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const double* p = partial + (size_t)(m / 64) * parts * 64 + (m % 64);
+    double s = 0.0;
+    for (int k = 0; k < parts; ++k) s += p[(size_t)k * 64];
+    var[m] = amp - s;
+}
+
 int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu, hipStream_t s) {
     if (M <= 0) return ALABI_OK;
     const int db = dim_bucket(gp->d);
@@ -525,6 +686,9 @@ int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu,
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }
+
+static int ensure_winv(alabi_gp* gp, hipStream_t s);
+static int ensure_small(alabi_gp* gp, size_t bytes, hipStream_t s);
 
 int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var, hipStream_t s) {
     if (M <= 0) return ALABI_OK;
@@ -566,12 +730,35 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
             }
             gp->ws_bytes = need;
         }
+        // Product with the cached L^-1 (no dependency between stages, block rows of a tile split over `parts` workgroups
+        // when the tiles alone cannot fill the chip); the substitution kernel when there is no room for the cache.
+        const char* envw = getenv("ALABI_PV_W");
+        int use_w = !(envw && envw[0] == '0');
+        if (use_w) {
+            const int stw = ensure_winv(gp, s);
+            if (stw == ALABI_NOT_COMPUTED) use_w = 0;
+            else if (stw != ALABI_OK) return stw;
+        }
         for (long long m0 = 0; m0 < M; m0 += chunk) {
             const long long mc = (M - m0 < chunk) ? M - m0 : chunk;
             const long long groups = (mc + 63) / 64;                               // K* workgroups (64 queries each)
+            const int TMc = use_w ? 64 : TM;
             ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_kstar_tile_kernel<D, GENERIC>),
                 dim3((unsigned)groups), dim3(256), 0, s, gp->Xt, gp->alpha, gp->N, gp->Npad, Xs + m0 * gp->d, gp->d, mc,
-                gp->inv_len, amp, gp->mean, gp->kf, gp->ws, mu + m0, TM)));
+                gp->inv_len, amp, gp->mean, gp->kf, gp->ws, mu + m0, TMc)));
+            if (use_w) {
+                const int nb = gp->Npad / 64;
+                int parts = 1;
+                if (groups < n_cu) { parts = (int)(n_cu / groups); if (parts > nb) parts = nb; if (parts < 1) parts = 1; }
+                const int gx = (int)(groups < n_cu ? groups : n_cu);
+                int st2 = ensure_small(gp, (size_t)groups * parts * 64 * sizeof(double), s);
+                if (st2 != ALABI_OK) return st2;
+                hipLaunchKernelGGL(predict_var_w_kernel, dim3(gx, parts), dim3(512), 0, s, gp->winv, gp->ws, gp->Npad, groups, parts,
+                                   gp->small);
+                hipLaunchKernelGGL(predict_var_w_final_kernel, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, s, gp->small, parts, mc,
+                                   amp, var + m0);
+                continue;
+            }
             const long long tiles_c = (mc + TM - 1) / TM;
             const int grid_c = (int)(tiles_c < n_cu ? tiles_c : n_cu);
             if (TM == 16)
@@ -694,8 +881,8 @@ predict_var_small_final_kernel(const double* __restrict__ partial, int nb, int M
     var[m] = amp - s;
 }
 
-int launch_predict_var_small(alabi_gp* gp, const double* Xs, int M, double* mu, double* var, hipStream_t s) {
-    const int nb = gp->Npad / 64, db = dim_bucket(gp->d);
+// The cached W = L^-1 of the current factor (tile-major, Npad^2 doubles); ALABI_NOT_COMPUTED when there is no room for it.
+static int ensure_winv(alabi_gp* gp, hipStream_t s) {
     const size_t need = (size_t)gp->Npad * gp->Npad * sizeof(double);
     if (need > gp->winv_bytes) {
         if (gp->winv) {
@@ -703,28 +890,40 @@ int launch_predict_var_small(alabi_gp* gp, const double* Xs, int M, double* mu, 
             ALABI_HIP_CHECK(hipFree(gp->winv));
             gp->winv = nullptr; gp->winv_bytes = 0;
         }
-        if (hipMalloc(&gp->winv, need) != hipSuccess) {     // no room for the cache: the substitution kernel does it
+        if (hipMalloc(&gp->winv, need) != hipSuccess) {
             (void)hipGetLastError();
             gp->winv = nullptr;
-            return launch_predict_var(gp, Xs, M, mu, var, s);
+            return ALABI_NOT_COMPUTED;
         }
         gp->winv_bytes = need;
         gp->winv_gen = -1;
     }
-    if (gp->small_bytes < (size_t)nb * 16 * sizeof(double)) {
-        if (gp->small) {
-            ALABI_HIP_CHECK(hipStreamSynchronize(s));
-            ALABI_HIP_CHECK(hipFree(gp->small));
-            gp->small = nullptr; gp->small_bytes = 0;
-        }
-        ALABI_HIP_CHECK(hipMalloc(&gp->small, (size_t)nb * 16 * sizeof(double)));
-        gp->small_bytes = (size_t)nb * 16 * sizeof(double);
-    }
-    int st;
     if (gp->winv_gen != gp->factor_gen) {
-        if ((st = launch_factor_inverse_into(gp, gp->winv, s)) != ALABI_OK) return st;
+        int st = launch_factor_inverse_into(gp, gp->winv, s);
+        if (st != ALABI_OK) return st;
         gp->winv_gen = gp->factor_gen;
     }
+    return ALABI_OK;
+}
+
+static int ensure_small(alabi_gp* gp, size_t bytes, hipStream_t s) {
+    if (gp->small_bytes >= bytes) return ALABI_OK;
+    if (gp->small) {
+        ALABI_HIP_CHECK(hipStreamSynchronize(s));
+        ALABI_HIP_CHECK(hipFree(gp->small));
+        gp->small = nullptr; gp->small_bytes = 0;
+    }
+    ALABI_HIP_CHECK(hipMalloc(&gp->small, bytes));
+    gp->small_bytes = bytes;
+    return ALABI_OK;
+}
+
+int launch_predict_var_small(alabi_gp* gp, const double* Xs, int M, double* mu, double* var, hipStream_t s) {
+    const int nb = gp->Npad / 64, db = dim_bucket(gp->d);
+    int st = ensure_winv(gp, s);
+    if (st == ALABI_NOT_COMPUTED) return launch_predict_var(gp, Xs, M, mu, var, s);   // no room: substitution kernel
+    if (st != ALABI_OK) return st;
+    if ((st = ensure_small(gp, (size_t)nb * 16 * sizeof(double), s)) != ALABI_OK) return st;
     if ((st = launch_predict_mean(gp, Xs, M, mu, s)) != ALABI_OK) return st;
     const double amp = exp(gp->log_amp);
     ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_var_small_kernel<D, GENERIC>), dim3(nb),

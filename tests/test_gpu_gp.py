@@ -269,10 +269,13 @@ def test_grad_log_likelihood_analytic():
     np.testing.assert_allclose(gf.grad_log_likelihood(y), ga[2:], rtol=1e-12)
 
 
+@pytest.mark.parametrize("w_path", ["1", "0"])
 @pytest.mark.parametrize("N", [1, 63, 64, 65, 128, 200, 256, 257, 320, 400, 700])
-def test_predict_variance_block_row_boundaries(N):
-    """The wave-specialised variance kernel runs block rows 0..3 one stage at a time and later rows two stages ahead:
-    training-set sizes on both sides of every boundary (1, 2, 4, 5, 7, 11 block rows, ragged last block)."""
+def test_predict_variance_block_row_boundaries(N, w_path, monkeypatch):
+    """Both wave-specialised variance kernels -- the product with the cached L^-1 (block rows split over workgroups) and the
+    substitution kernel (block rows 0..3 one stage at a time, later rows two stages ahead) -- at training-set sizes on both
+    sides of every boundary (1, 2, 4, 5, 7, 11 block rows, ragged last block)."""
+    monkeypatch.setenv("ALABI_PV_W", w_path)
     from alabi_amd import HipGP
     from oracle.gp_oracle import OracleGP
     X, y, h = make_problem(N, 3, 100 + N, log_wn=-8.0)
@@ -296,19 +299,23 @@ def test_predict_variance_paths_agree(monkeypatch):
     X, y, h = make_problem(500, 6, 8, log_wn=-8.0)
     Xs = np.random.RandomState(3).uniform(-3, 3, (5000, 6))
     out = {}
-    for tag, env in (("default", {}), ("chunked", {"ALABI_PV_CHUNK_TILES": "7"}), ("legacy", {"ALABI_PV_LEGACY": "1"})):
-        for k in ("ALABI_PV_CHUNK_TILES", "ALABI_PV_LEGACY"):
+    for tag, env in (("default", {}), ("chunked", {"ALABI_PV_CHUNK_TILES": "7"}), ("legacy", {"ALABI_PV_LEGACY": "1"}),
+                     ("substitution", {"ALABI_PV_W": "0"}), ("substitution_chunked", {"ALABI_PV_W": "0", "ALABI_PV_CHUNK_TILES": "7"})):
+        for k in ("ALABI_PV_CHUNK_TILES", "ALABI_PV_LEGACY", "ALABI_PV_W"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         g = HipGP(6, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
         out[tag] = g.predict(y, Xs, return_var=True)
     amp = np.exp(h["log_amp"])
-    np.testing.assert_array_equal(out["default"][1], out["chunked"][1])
+    # a chunk of 7 tiles splits each tile's block rows over more workgroups than the default launch: same sums, other order
+    assert np.max(np.abs(out["default"][1] - out["chunked"][1])) <= 1e-12 * amp
     np.testing.assert_array_equal(out["default"][0], out["chunked"][0])
     assert np.max(np.abs(out["default"][1] - out["legacy"][1])) <= 1e-9 * amp
     assert np.max(np.abs(out["default"][0] - out["legacy"][0])) <= 1e-9 * (np.max(np.abs(out["legacy"][0])) + 1)
-    for k in ("ALABI_PV_CHUNK_TILES", "ALABI_PV_LEGACY"):
+    assert np.max(np.abs(out["default"][1] - out["substitution"][1])) <= 1e-9 * amp
+    np.testing.assert_array_equal(out["substitution"][1], out["substitution_chunked"][1])
+    for k in ("ALABI_PV_CHUNK_TILES", "ALABI_PV_LEGACY", "ALABI_PV_W"):
         monkeypatch.delenv(k, raising=False)
     X2, y2, h2 = make_problem(300, 20, 9, log_wn=-8.0, ell2=20.0)
     g2 = HipGP(20, h2["mean"], h2["log_white_noise"], h2["log_amp"], h2["log_M"]); g2.compute(X2)
