@@ -1,7 +1,9 @@
 // extern "C" entry points of libalabi_hip.so (declared in include/alabi_hip.h).
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <new>
+#include <vector>
 
 #include "gp_device.hpp"
 
@@ -16,6 +18,49 @@ copy_factor_kernel(const double* __restrict__ L, int ld, int N, double* __restri
     if (e >= (size_t)N * N) return;
     int r = (int)(e / N), c = (int)(e % N);
     out[e] = (c <= r) ? L[(size_t)r * ld + c] : 0.0;
+}
+
+namespace {
+struct CachedBuf { void* p; size_t bytes; };
+std::mutex g_cache_mu;
+std::vector<CachedBuf> g_cache;        // at most 4 buffers, the smallest is dropped first
+}
+
+void* dev_cache_take(size_t need, size_t* bytes) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    int best = -1;
+    for (int i = 0; i < (int)g_cache.size(); ++i)
+        if (g_cache[i].bytes >= need && (best < 0 || g_cache[i].bytes < g_cache[best].bytes)) best = i;
+    if (best < 0) return nullptr;
+    void* p = g_cache[best].p;
+    *bytes = g_cache[best].bytes;
+    g_cache.erase(g_cache.begin() + best);
+    return p;
+}
+
+void dev_cache_give(void* p, size_t bytes) {
+    if (!p) return;
+    void* drop = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        g_cache.push_back({p, bytes});
+        if (g_cache.size() > 4) {
+            int sm = 0;
+            for (int i = 1; i < (int)g_cache.size(); ++i) if (g_cache[i].bytes < g_cache[sm].bytes) sm = i;
+            drop = g_cache[sm].p;
+            g_cache.erase(g_cache.begin() + sm);
+        }
+    }
+    if (drop) (void)hipFree(drop);
+}
+
+int dev_alloc_cached(void** p, size_t need, size_t* bytes) {
+    *p = dev_cache_take(need, bytes);
+    if (*p) return (int)hipSuccess;
+    const hipError_t e = hipMalloc(p, need);
+    if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; *bytes = 0; return (int)e; }
+    *bytes = need;
+    return (int)hipSuccess;
 }
 
 static int fill_dimvec(DimVec& v, const double* src, int d, int stride, int off, double pad) {
@@ -95,9 +140,10 @@ int alabi_gp_destroy(alabi_gp* gp) {
     if (gp->flags) (void)hipFree(gp->flags);
     if (gp->red) (void)hipFree(gp->red);
     if (gp->info) (void)hipFree(gp->info);
-    if (gp->ws) (void)hipFree(gp->ws);
+    if (gp->ws || gp->winv) (void)hipDeviceSynchronize();   // nothing in flight may still use the buffers handed to the cache
+    alabi::dev_cache_give(gp->ws, gp->ws_bytes);
     if (gp->scan) (void)hipFree(gp->scan);
-    if (gp->winv) (void)hipFree(gp->winv);
+    alabi::dev_cache_give(gp->winv, gp->winv_bytes);
     if (gp->small) (void)hipFree(gp->small);
     delete gp;
     return ALABI_OK;

@@ -143,6 +143,11 @@ int launch_alpha(alabi_gp* gp, hipStream_t s);
 int launch_reductions(alabi_gp* gp, hipStream_t s);
 // gp_predict.hip
 int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu, hipStream_t s);
+// Process-wide cache of the large scratch buffers (variance workspace, cached L^-1): the reference creates a new GP object
+// for every refit (gp_utils.py:233), and a 1-2 GiB hipMalloc per new handle costs tens of milliseconds.
+void* dev_cache_take(size_t need, size_t* bytes);   // a cached buffer of at least `need` bytes, or nullptr
+void dev_cache_give(void* p, size_t bytes);         // hand a buffer back (may free it or another one)
+int dev_alloc_cached(void** p, size_t need, size_t* bytes);   // cache first, then hipMalloc; hipError_t as int
 int launch_factor_inverse(alabi_gp* gp, hipStream_t s);
 int launch_factor_inverse_into(alabi_gp* gp, double* dst, hipStream_t s);
 int launch_predict_var_small(alabi_gp* gp, const double* Xs, int M, double* mu, double* var, hipStream_t s);

@@ -716,19 +716,18 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
         if (need > gp->ws_bytes) {
             if (gp->ws) {
                 ALABI_HIP_CHECK(hipStreamSynchronize(s));
-                ALABI_HIP_CHECK(hipFree(gp->ws));
+                dev_cache_give(gp->ws, gp->ws_bytes);
                 gp->ws = nullptr; gp->ws_bytes = 0;
             }
             // short of memory: halve the chunk down to one round over the CUs before giving up
-            while (hipMalloc(&gp->ws, need) != hipSuccess) {
-                (void)hipGetLastError();
-                gp->ws = nullptr;
+            size_t got = 0;
+            while (dev_alloc_cached((void**)&gp->ws, need, &got) != (int)hipSuccess) {
                 if (chunk <= 64LL * n_cu) return ALABI_HIP_ERROR;
                 chunk = (chunk / 2 + 63) / 64 * 64;
                 if (chunk < 64LL * n_cu) chunk = 64LL * n_cu;
                 need = (size_t)(chunk / 64) * gp->Npad * 64 * sizeof(double);
             }
-            gp->ws_bytes = need;
+            gp->ws_bytes = got;
         }
         // Product with the cached L^-1 (no dependency between stages, block rows of a tile split over `parts` workgroups
         // when the tiles alone cannot fill the chip); the substitution kernel when there is no room for the cache.
@@ -776,11 +775,12 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
     if (need > gp->ws_bytes) {
         if (gp->ws) {
             ALABI_HIP_CHECK(hipStreamSynchronize(s));
-            ALABI_HIP_CHECK(hipFree(gp->ws));
+            dev_cache_give(gp->ws, gp->ws_bytes);
             gp->ws = nullptr; gp->ws_bytes = 0;
         }
-        ALABI_HIP_CHECK(hipMalloc(&gp->ws, need));
-        gp->ws_bytes = need;
+        size_t got = 0;
+        if (dev_alloc_cached((void**)&gp->ws, need, &got) != (int)hipSuccess) return ALABI_HIP_ERROR;
+        gp->ws_bytes = got;
     }
     int split = 0;   // ablation knob for tools/prof_predict.py only (results are wrong unless 0)
     if (const char* env = getenv("ALABI_PV_ABLATE")) split = atoi(env);
@@ -808,11 +808,12 @@ int launch_factor_inverse(alabi_gp* gp, hipStream_t s) {
     if (need > gp->ws_bytes) {
         if (gp->ws) {
             ALABI_HIP_CHECK(hipStreamSynchronize(s));
-            ALABI_HIP_CHECK(hipFree(gp->ws));
+            dev_cache_give(gp->ws, gp->ws_bytes);
             gp->ws = nullptr; gp->ws_bytes = 0;
         }
-        ALABI_HIP_CHECK(hipMalloc(&gp->ws, need));
-        gp->ws_bytes = need;
+        size_t got = 0;
+        if (dev_alloc_cached((void**)&gp->ws, need, &got) != (int)hipSuccess) return ALABI_HIP_ERROR;
+        gp->ws_bytes = got;
     }
     return launch_factor_inverse_into(gp, gp->ws, s);
 }
@@ -887,15 +888,12 @@ static int ensure_winv(alabi_gp* gp, hipStream_t s) {
     if (need > gp->winv_bytes) {
         if (gp->winv) {
             ALABI_HIP_CHECK(hipStreamSynchronize(s));
-            ALABI_HIP_CHECK(hipFree(gp->winv));
+            dev_cache_give(gp->winv, gp->winv_bytes);
             gp->winv = nullptr; gp->winv_bytes = 0;
         }
-        if (hipMalloc(&gp->winv, need) != hipSuccess) {
-            (void)hipGetLastError();
-            gp->winv = nullptr;
-            return ALABI_NOT_COMPUTED;
-        }
-        gp->winv_bytes = need;
+        size_t got = 0;
+        if (dev_alloc_cached((void**)&gp->winv, need, &got) != (int)hipSuccess) return ALABI_NOT_COMPUTED;
+        gp->winv_bytes = got;
         gp->winv_gen = -1;
     }
     if (gp->winv_gen != gp->factor_gen) {
