@@ -17,6 +17,7 @@
 namespace alabi {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 // f(r2) and f'(r2) of the four kernels (gp_device.hpp: radial)
 __device__ inline void radial_with_derivative(double r2, KernelFn kf, double& f, double& df, double& dlog_alpha) {
@@ -53,25 +54,43 @@ grad_contract_kernel(const double* __restrict__ W, const double* __restrict__ Xt
         xb_s[e >> 6][e & 63] = Xt[(size_t)(e >> 6) * Npad + tb * 64 + (e & 63)];
     }
     if (tid < 64) { al_a[tid] = alpha[ta * 64 + tid]; al_b[tid] = alpha[tb * 64 + tid]; }
-    // K^-1 block: wave w owns rows 16w..16w+15, four 16-column tiles.  MFMA operand layout (gfx950, 16x16x4 f64):
-    // A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k, C[(lane >> 4) + 4 i][lane & 15] in element i.
-    const double* Wa = W + (size_t)ta * Npad * 64 + 16 * w + (l & 15);
-    const double* Wb = W + (size_t)tb * Npad * 64 + (l & 15);
+    // K^-1 block = sum over 64-row slabs n0 >= 64 ta of Wa_slab^T Wb_slab: both slabs (64 x 64, row n, column a / b) are
+    // staged in LDS through registers one slab ahead (16-byte coalesced loads), wave w owns output rows 16w..16w+15, four
+    // 16-column tiles.  MFMA operand layout (gfx950, 16x16x4 f64): A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k,
+    // C[(lane >> 4) + 4 i][lane & 15] in element i; with the slabs stored [k][i] both operands are conflict-free row reads.
+    __shared__ double Sa[64][66], Sb[64][66];
+    const f64x2* Wa2 = reinterpret_cast<const f64x2*>(W + (size_t)ta * Npad * 64);
+    const f64x2* Wb2 = reinterpret_cast<const f64x2*>(W + (size_t)tb * Npad * 64);
     v4f64 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = v4f64{0.0, 0.0, 0.0, 0.0};
-    for (int n = ta * 64 + (l >> 4); n < Npad; n += 16) {
-        double a[4], b[4][4];
+    f64x2 pa[8], pb[8];
+    {
+        const size_t base = (size_t)(ta * 64) * 32;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            a[u] = Wa[(size_t)(n + 4 * u) * 64];
+        for (int i = 0; i < 8; ++i) { pa[i] = Wa2[base + tid + 256 * i]; pb[i] = Wb2[base + tid + 256 * i]; }
+    }
+    for (int n0 = ta * 64; n0 < Npad; n0 += 64) {
+        __syncthreads();                               // the previous slab's MFMAs are done with Sa / Sb
 #pragma unroll
-            for (int c = 0; c < 4; ++c) b[u][c] = Wb[(size_t)(n + 4 * u) * 64 + 16 * c];
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i, r = e >> 5, c2 = e & 31;
+            *reinterpret_cast<f64x2*>(&Sa[r][2 * c2]) = pa[i];
+            *reinterpret_cast<f64x2*>(&Sb[r][2 * c2]) = pb[i];
+        }
+        __syncthreads();
+        if (n0 + 64 < Npad) {
+            const size_t base = (size_t)(n0 + 64) * 32;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { pa[i] = Wa2[base + tid + 256 * i]; pb[i] = Wb2[base + tid + 256 * i]; }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int ks = 0; ks < 16; ++ks) {
+            const double a = Sa[4 * ks + (l >> 4)][16 * w + (l & 15)];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][c], acc[c], 0, 0, 0);
+            for (int c = 0; c < 4; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Sb[4 * ks + (l >> 4)][16 * c + (l & 15)], acc[c], 0, 0, 0);
+        }
     }
     __syncthreads();
     double s_amp = 0.0, s_tr = 0.0, s_al = 0.0, s_m[D];
@@ -130,8 +149,14 @@ grad_final_kernel(const double* __restrict__ partial, int nblocks, int stride, c
 }
 
 int launch_grad_log_likelihood(alabi_gp* gp, double* grad_dev, hipStream_t s) {
-    int st = launch_factor_inverse(gp, s);
-    if (st != ALABI_OK) return st;
+    // L^-1: the cache the variance path keeps per factor; into the variance workspace when there is no room for the cache
+    const double* Wsrc = nullptr;
+    int st = ensure_winv(gp, s);
+    if (st == ALABI_OK) Wsrc = gp->winv;
+    else if (st == ALABI_NOT_COMPUTED) {
+        if ((st = launch_factor_inverse(gp, s)) != ALABI_OK) return st;
+        Wsrc = gp->ws;
+    } else return st;
     const int nb = gp->Npad / 64, nblocks = nb * (nb + 1) / 2;
     const int db = dim_bucket(gp->d);
     const size_t need = (size_t)nblocks * (db + 3) * sizeof(double);
@@ -145,7 +170,7 @@ int launch_grad_log_likelihood(alabi_gp* gp, double* grad_dev, hipStream_t s) {
         gp->scan_bytes = need;
     }
     const double amp = exp(gp->log_amp), wn = exp(gp->log_wn);
-    ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(grad_contract_kernel<D>, dim3(nblocks), dim3(256), 0, s, gp->ws, gp->Xt, gp->alpha,
+    ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(grad_contract_kernel<D>, dim3(nblocks), dim3(256), 0, s, Wsrc, gp->Xt, gp->alpha,
                                               gp->N, gp->Npad, amp, gp->kf, gp->scan));
     hipLaunchKernelGGL(grad_final_kernel, dim3(1), dim3(256), 0, s, gp->scan, nblocks, db + 3, gp->alpha, gp->N, wn, gp->d,
                        grad_dev);

@@ -687,7 +687,7 @@ int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu,
     return ALABI_OK;
 }
 
-static int ensure_winv(alabi_gp* gp, hipStream_t s);
+int ensure_winv(alabi_gp* gp, hipStream_t s);
 static int ensure_small(alabi_gp* gp, size_t bytes, hipStream_t s);
 
 int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var, hipStream_t s) {
@@ -791,10 +791,57 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
     return ALABI_OK;
 }
 
-// L^-1 tile-major into dst: dst[t] = L^-1[:, 64t:64t+64] as [Npad][64] (rows above block t unspecified, the upper part
-// of the diagonal block exact zeros).
+__global__ void __launch_bounds__(256)
+ident_seed_kernel(double* __restrict__ seeds, int Npad) {
+    // 16-wide tiles: seeds[t][n][c] = (n == 16 t + c)
+    const size_t n_el = (size_t)Npad * Npad;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n_el; e += (size_t)gridDim.x * 256) {
+        const size_t t = e / ((size_t)Npad * 16), rem = e % ((size_t)Npad * 16);
+        seeds[e] = ((rem >> 4) == 16 * t + (rem & 15)) ? 1.0 : 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+retile_16_to_64_kernel(const double* __restrict__ src, double* __restrict__ dst, int Npad) {
+    // src[t16][n][16] -> dst[t64][n][64]
+    const size_t n_el = (size_t)Npad * Npad;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n_el; e += (size_t)gridDim.x * 256) {
+        const size_t t64 = e / ((size_t)Npad * 64), rem = e % ((size_t)Npad * 64);
+        const size_t n = rem >> 6, c = rem & 63;
+        dst[e] = src[((t64 * 4 + (c >> 4)) * Npad + n) * 16 + (c & 15)];
+    }
+}
+
+// L^-1 tile-major into dst: dst[t] = L^-1[:, 64t:64t+64] as [Npad][64].  The columns of the identity are pushed through the
+// wave-specialised substitution kernel as 16-wide tiles (Npad / 16 independent workgroups, 1.3 us per stage) into the
+// variance workspace and re-tiled; the first-generation kernel (Npad / 64 workgroups, 3.3 us per stage) when the workspace
+// cannot be had.
 int launch_factor_inverse_into(alabi_gp* gp, double* dst, hipStream_t s) {
     const int nb = gp->Npad / 64;
+    const size_t need = (size_t)gp->Npad * gp->Npad * sizeof(double);
+    bool fast = dst != gp->ws && nb >= 5;
+    if (fast && need > gp->ws_bytes) {
+        if (gp->ws) {
+            ALABI_HIP_CHECK(hipStreamSynchronize(s));
+            dev_cache_give(gp->ws, gp->ws_bytes);
+            gp->ws = nullptr; gp->ws_bytes = 0;
+        }
+        size_t got = 0;
+        if (dev_alloc_cached((void**)&gp->ws, need, &got) != (int)hipSuccess) fast = false;
+        else gp->ws_bytes = got;
+    }
+    if (fast) {
+        int dev = 0, n_cu = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        const int tiles = gp->Npad / 16;
+        hipLaunchKernelGGL(ident_seed_kernel, dim3(1024), dim3(256), 0, s, gp->ws, gp->Npad);
+        hipLaunchKernelGGL(predict_var_ws_kernel<16>, dim3(tiles < n_cu ? tiles : n_cu), dim3(512), 0, s, gp->L, gp->dinv, gp->Npad,
+                           (long long)gp->Npad, 0.0, gp->ws, gp->work);
+        hipLaunchKernelGGL(retile_16_to_64_kernel, dim3(1024), dim3(256), 0, s, gp->ws, dst, gp->Npad);
+        ALABI_LAUNCH_CHECK();
+        return ALABI_OK;
+    }
     hipLaunchKernelGGL((predict_var_kernel<1, true>), dim3(nb), dim3(256), 0, s, gp->L, gp->dinv, gp->Xt, gp->alpha, gp->N,
                        gp->Npad, (const double*)nullptr, gp->d, (long long)gp->Npad, gp->inv_len, 1.0, 0.0, dst,
                        (double*)nullptr, (double*)nullptr, 0, gp->kf);
@@ -883,7 +930,7 @@ predict_var_small_final_kernel(const double* __restrict__ partial, int nb, int M
 }
 
 // The cached W = L^-1 of the current factor (tile-major, Npad^2 doubles); ALABI_NOT_COMPUTED when there is no room for it.
-static int ensure_winv(alabi_gp* gp, hipStream_t s) {
+int ensure_winv(alabi_gp* gp, hipStream_t s) {
     const size_t need = (size_t)gp->Npad * gp->Npad * sizeof(double);
     if (need > gp->winv_bytes) {
         if (gp->winv) {
