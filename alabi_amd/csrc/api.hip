@@ -523,7 +523,7 @@ int alabi_ens_run(alabi_ens* e, double* coords, double* logp, long long step0, l
     int st;
     if ((st = sync_consts(e, s)) != ALABI_OK) return st;
     if ((st = set_run_state(e, step0, 0, s)) != ALABI_OK) return st;
-    // Persistent dataflow path: training set pinned in registers (needs Npad <= 2 points x 1024 lanes), one
+    // Persistent dataflow path: training set pinned in registers (Npad <= 2048: 256 compute lanes x up to 4 point pairs), one
     // workgroup per list position.  It synchronises at the end to read the time-out flag.
     e->last_path = 0;
     if (e->stream_ok && s != nullptr && ens_stream_fits(e)) {
