@@ -381,8 +381,9 @@ int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* 
     }
     // 256 compute lanes (up to 4 point pairs each) cover Npad <= 2048: few, fat waves keep the per-wave overhead of a
     // proposal (broadcast, DPP reduction) small -- measured 2.00 us per half step against 2.11 us with 512 lanes.
-    // Larger training sets use full 1024-lane workgroups on the launch-per-half-step path.
-    e->threads = (gp->Npad / 2 <= 1024) ? 256 : 1024;
+    // Larger training sets run on the launch-per-half-step path with 512-lane workgroups (room for several proposals per
+    // workgroup in ens_half_multi_kernel).
+    e->threads = (gp->Npad / 2 <= 1024) ? 256 : 512;
     if (const char* env = getenv("ALABI_ENS_THREADS")) {
         int v = atoi(env);
         if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) e->threads = v;

@@ -174,6 +174,7 @@ struct HalfArgs {
     long long* n_accept;         // [E*W] or null
     const long long* run_state;  // [0] chunk's first global step, [1] steps done before the chunk
     int n0, W, d, Npad, split, part_begin, local_t, thin_by;
+    int count;                   // proposals in this launch (several per workgroup in ens_half_multi_kernel)
     double amp, mean;
     KernelFn kf;
 };

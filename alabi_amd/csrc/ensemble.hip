@@ -260,6 +260,128 @@ ens_half_kernel(HalfArgs p) {
     }
 }
 
+// NP proposals of the same half step per workgroup: the training set is streamed ONCE per workgroup and used for all of them.
+// With more proposals than CUs (W/2 > 256, or E ensembles) ens_half_kernel is bound by L2 -> CU bandwidth: every workgroup
+// pulls the whole X (440 KB at N = 5000, d = 10) for one proposal.  Per proposal the arithmetic, the lane -> point map and the
+// reduction order are those of ens_half_kernel with the same block size, so the two kernels agree bit for bit.
+template <int D, bool GENERIC, int NP>
+__global__ void __launch_bounds__(512)
+ens_half_multi_kernel(HalfArgs p) {
+    __shared__ double q_s[NP][ALABI_MAX_DIM], qs_s[NP][ALABI_MAX_DIM], old_s[NP][ALABI_MAX_DIM];
+    __shared__ double scratch[NP][16];
+    __shared__ int ok_s[NP], w_s[NP];
+    __shared__ double lpold_s[NP], lnfac_s[NP], lnu_s[NP];
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int e = blockIdx.y;
+    const int first = blockIdx.x * NP;
+    const double* inv_len = p.consts;
+    const double* lo = p.consts + ALABI_MAX_DIM;
+    const double* hi = p.consts + 2 * ALABI_MAX_DIM;
+    if (tid < NP) ok_s[tid] = 1;
+    __syncthreads();
+    // (1) the NP proposals: thread (pp, k) forms coordinate k of proposal pp
+    for (int idx = tid; idx < NP * D; idx += T) {
+        const int pp = idx / D, k = idx % D;
+        int w = -1;
+        if (first + pp < p.count) {
+            const size_t pos = (size_t)e * p.W + (p.split ? p.n0 : 0) + p.part_begin + first + pp;
+            w = p.rec.order[pos];
+            if (w >= 0) {
+                double qv = 0.0;
+                if (k < p.d) {
+                    const int cw = p.rec.cw[pos];
+                    const double zz = p.rec.zz[pos];
+                    const double cv = p.coords[(size_t)cw * p.d + k];
+                    const double sv = p.coords[(size_t)w * p.d + k];
+                    qv = cv - (cv - sv) * zz;
+                    if (!((qv > lo[k]) && (qv < hi[k]))) ok_s[pp] = 0;
+                    q_s[pp][k] = qv; old_s[pp][k] = sv;
+                    qv *= inv_len[k];
+                }
+                qs_s[pp][k] = qv;
+                if (k == 0) { lpold_s[pp] = p.logp[w]; lnfac_s[pp] = p.rec.lnfac[pos]; lnu_s[pp] = p.rec.lnu[pos]; }
+            }
+        }
+        if (k == 0) w_s[pp] = w;
+    }
+    __syncthreads();
+    // (2) kernel sums: X pairs streamed once, NP accumulators
+    double q[NP][D];
+    bool live[NP];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+        live[pp] = w_s[pp] >= 0 && ok_s[pp];
+#pragma unroll
+        for (int k = 0; k < D; ++k) q[pp][k] = qs_s[pp][k];
+    }
+    double acc[NP];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) acc[pp] = 0.0;
+    const int half = p.Npad >> 1;
+    bool first_pair = true;
+    for (int j = tid; j < half; j += T) {
+        f64x2 x[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = reinterpret_cast<const f64x2*>(p.Xt + (size_t)k * p.Npad)[j];
+        const f64x2 al = reinterpret_cast<const f64x2*>(p.alpha)[j];
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double d0 = x[k].x - q[pp][k], d1 = x[k].y - q[pp][k];
+                s0 = fma(d0, d0, s0);
+                s1 = fma(d1, d1, s1);
+            }
+            // ens_half_kernel's order: the lane's first pair enters by a multiply, every later term by an fma
+            acc[pp] = first_pair ? al.x * radial<GENERIC>(s0, p.kf) : fma(al.x, radial<GENERIC>(s0, p.kf), acc[pp]);
+            acc[pp] = fma(al.y, radial<GENERIC>(s1, p.kf), acc[pp]);
+        }
+        first_pair = false;
+    }
+    // a lane without any pair (tid >= half) contributes aa = 0: 0 * f + 0 * f = 0 exactly, as in ens_half_kernel
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+        const double wsum = wave_sum_dpp(acc[pp]);
+        if ((tid & 63) == 63) scratch[pp][tid >> 6] = wsum;
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    // (3) wave 0: accept tests and state updates, one proposal after the other
+    const int nw = T >> 6;
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+        const int w = w_s[pp];
+        if (w < 0) continue;                              // beyond the launch's proposals, or an inert record
+        double lp_new = -INFINITY;
+        if (ok_s[pp]) {
+            double part = (tid < nw) ? scratch[pp][tid] : 0.0;
+            part = wave_sum_dpp(part);
+            lp_new = fma(p.amp, lane_bcast(part, 63), p.mean);
+        }
+        const double lp_old = lpold_s[pp];
+        const int acc_flag = (lnfac_s[pp] + lp_new - lp_old > lnu_s[pp]) ? 1 : 0;
+        if (acc_flag) {
+            if (tid < p.d) p.coords[(size_t)w * p.d + tid] = q_s[pp][tid];
+            if (tid == 0) {
+                p.logp[w] = lp_new;
+                if (p.n_accept) p.n_accept[w] += 1;
+            }
+        }
+        if (p.chain || p.chain_logp) {
+            const long long done = p.run_state[1] + p.local_t + 1;
+            if (done % p.thin_by == 0) {
+                const size_t slot = (size_t)(done / p.thin_by - 1);
+                const size_t WT = (size_t)p.W * gridDim.y;
+                if (p.chain && tid < p.d)
+                    __builtin_nontemporal_store(acc_flag ? q_s[pp][tid] : old_s[pp][tid], &p.chain[(slot * WT + w) * p.d + tid]);
+                if (p.chain_logp && tid == 0)
+                    __builtin_nontemporal_store(acc_flag ? lp_new : lp_old, &p.chain_logp[slot * WT + w]);
+            }
+        }
+    }
+}
+
 template <int D>
 __global__ void __launch_bounds__(1024)
 ens_lnprob_kernel(const double* __restrict__ coords, int d, const double* __restrict__ Xt,
@@ -705,11 +827,34 @@ int launch_ens_prep(alabi_ens* e, const int* order, int n0, const double* u_z, c
     return ALABI_OK;
 }
 
-int launch_ens_half_args(alabi_ens* e, const HalfArgs& args, int nblocks, hipStream_t s) {
+int launch_ens_half_args(alabi_ens* e, const HalfArgs& args_in, int nblocks, hipStream_t s) {
     if (nblocks <= 0) return ALABI_OK;
     const int db = dim_bucket(e->d);
     const int threads = e->threads;
-    ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(e->gp->kf.type, hipLaunchKernelGGL((ens_half_kernel<D, GENERIC>), dim3(nblocks, e->E), dim3(threads), 0, s, args)));
+    HalfArgs args = args_in;
+    args.count = nblocks;
+    // more proposals than CUs: NP per workgroup share one pass over the training set (same block size: same bits)
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    const long long total = (long long)nblocks * e->E;
+    const char* env = getenv("ALABI_ENS_MULTI");
+    int np = 1;
+    if (threads <= 512 && db <= 24 && !(env && env[0] == '0')) {
+        if (total > 3LL * n_cu && db <= 16) np = 4; else if (total > n_cu) np = 2;   // q[NP][D] lives in registers
+    }
+    if (np == 4) {
+        ALABI_STREAM_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(e->gp->kf.type, hipLaunchKernelGGL((ens_half_multi_kernel<D, GENERIC, 4>),
+            dim3((nblocks + 3) / 4, e->E), dim3(threads), 0, s, args)));
+    } else if (np == 2) {
+        ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(e->gp->kf.type, hipLaunchKernelGGL((ens_half_multi_kernel<D, GENERIC, 2>),
+            dim3((nblocks + 1) / 2, e->E), dim3(threads), 0, s, args)));
+    } else {
+        ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(e->gp->kf.type, hipLaunchKernelGGL((ens_half_kernel<D, GENERIC>), dim3(nblocks, e->E), dim3(threads), 0, s, args)));
+    }
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

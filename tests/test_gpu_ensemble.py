@@ -227,3 +227,23 @@ def test_persistent_kernel_timeout_falls_back(monkeypatch):
     monkeypatch.delenv("ALABI_ENS_SPIN_LIMIT")
     s.run_mcmc(None, 40); ref.run_mcmc(None, 40)              # the sampler stays on the fallback path and keeps going
     np.testing.assert_array_equal(s.get_chain(), ref.get_chain())
+
+
+@pytest.mark.parametrize("W,E", [(40, 16), (36, 32), (700, 1)])
+def test_multi_proposal_half_step_bit_identical(W, E, monkeypatch):
+    """More proposals than CUs per half step: ens_half_multi_kernel (2 or 4 proposals per workgroup sharing one pass over the
+    training set) must reproduce ens_half_kernel bit for bit (ragged last workgroup included)."""
+    from alabi_amd import EnsembleSampler, HipGP
+    X, y, h = make_problem(260, 4, 21, log_wn=-9.0)
+    g = HipGP(4, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+    bounds = np.array([[-3.0, 3.0]] * 4)
+    p0 = np.random.RandomState(5).uniform(-2, 2, (W * E, 4))
+    monkeypatch.setenv("ALABI_ENS_STREAM", "0")
+    out = {}
+    for multi in ("0", "1"):
+        monkeypatch.setenv("ALABI_ENS_MULTI", multi)
+        s = EnsembleSampler(W, 4, g, y, bounds, seed=8, n_ensembles=E)
+        s.run_mcmc(p0, 40)
+        out[multi] = (s.get_chain(), s.get_log_prob(), s.acceptance_fraction)
+    for a, b in zip(out["0"], out["1"]):
+        np.testing.assert_array_equal(a, b)
