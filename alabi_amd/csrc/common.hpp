@@ -81,6 +81,8 @@ struct alabi_gp {
     size_t winv_bytes = 0;
     long long factor_gen = 0; // bumped by every successful compute
     long long winv_gen = -1;  // factor_gen the cached L^-1 belongs to
+    long long req_gen = -1;   // factor_gen the counter below belongs to
+    int var_requests = 0;     // variance requests seen for the current factor (decides when the cache pays)
     double* small = nullptr;  // [Npad / 64][16] partial sums of the small-batch variance kernel
     size_t small_bytes = 0;
 };
@@ -149,6 +151,7 @@ void* dev_cache_take(size_t need, size_t* bytes);   // a cached buffer of at lea
 void dev_cache_give(void* p, size_t bytes);         // hand a buffer back (may free it or another one)
 int dev_alloc_cached(void** p, size_t need, size_t* bytes);   // cache first, then hipMalloc; hipError_t as int
 int launch_factor_inverse(alabi_gp* gp, hipStream_t s);
+int want_winv(alabi_gp* gp, long long M);            // counts the request; 1 when the cached L^-1 should serve it
 int ensure_winv(alabi_gp* gp, hipStream_t s);        // the cached L^-1 of the current factor in gp->winv (ALABI_NOT_COMPUTED: no room)
 int launch_factor_inverse_into(alabi_gp* gp, double* dst, hipStream_t s);
 int launch_predict_var_small(alabi_gp* gp, const double* Xs, int M, double* mu, double* var, hipStream_t s);

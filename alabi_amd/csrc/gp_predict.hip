@@ -690,6 +690,17 @@ int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu,
 int ensure_winv(alabi_gp* gp, hipStream_t s);
 static int ensure_small(alabi_gp* gp, size_t bytes, hipStream_t s);
 
+// Should this variance request go through the cached L^-1?  (see the comment in launch_predict_var)
+int want_winv(alabi_gp* gp, long long M) {
+    const char* envw = getenv("ALABI_PV_W");
+    if (gp->req_gen != gp->factor_gen) { gp->req_gen = gp->factor_gen; gp->var_requests = 0; }
+    gp->var_requests++;
+    if (envw && envw[0] == '0') return 0;
+    if (envw && envw[0] == '1') return 1;
+    const bool cached = gp->winv && gp->winv_gen == gp->factor_gen;
+    return (cached || gp->var_requests >= 2 || (gp->Npad <= 2048 && M <= 16384)) ? 1 : 0;
+}
+
 int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var, hipStream_t s) {
     if (M <= 0) return ALABI_OK;
     const int db = dim_bucket(gp->d);
@@ -731,8 +742,11 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
         }
         // Product with the cached L^-1 (no dependency between stages, block rows of a tile split over `parts` workgroups
         // when the tiles alone cannot fill the chip); the substitution kernel when there is no room for the cache.
-        const char* envw = getenv("ALABI_PV_W");
-        int use_w = !(envw && envw[0] == '0');
+        // Building the cache costs a latency-bound N^3/3 (0.7 ms at N = 2000, 8 ms at N = 5000): worth it when it is there
+        // already (the gradient built it, or an earlier request), for the second and later requests on one factor, and for
+        // small batches on small factors straight away; a single large scan on a fresh factor goes through the substitution
+        // kernel.  ALABI_PV_W=1 forces the cache, =0 forbids it.
+        int use_w = want_winv(gp, M);
         if (use_w) {
             const int stw = ensure_winv(gp, s);
             if (stw == ALABI_NOT_COMPUTED) use_w = 0;
