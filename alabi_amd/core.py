@@ -41,6 +41,30 @@ def _is_identity(scaler, probe):
         return False
 
 
+def _affine_map(fn, box):
+    """(mult, add) with fn(x) == mult * x + add per column on `box` ([d, 2] lower / upper), or None if fn is not an
+    increasing-or-decreasing affine map per dimension there (checked at three interior points)."""
+    try:
+        box = np.asarray(box, dtype=np.float64).reshape(-1, 2)
+        lo, hi = box[:, 0], box[:, 1]
+        f_lo = np.asarray(fn(lo.reshape(1, -1)), dtype=np.float64).reshape(-1)
+        f_hi = np.asarray(fn(hi.reshape(1, -1)), dtype=np.float64).reshape(-1)
+        if f_lo.shape != lo.shape or np.any(hi == lo):
+            return None
+        mult = (f_hi - f_lo) / (hi - lo)
+        add = f_lo - mult * lo
+        if not (np.all(np.isfinite(mult)) and np.all(np.isfinite(add)) and np.all(mult != 0)):
+            return None
+        for frac in (0.25, 0.5, 0.8):
+            x = lo + frac * (hi - lo)
+            fx = np.asarray(fn(x.reshape(1, -1)), dtype=np.float64).reshape(-1)
+            if not np.allclose(fx, mult * x + add, rtol=1e-11, atol=1e-11 * (np.abs(f_hi) + np.abs(f_lo) + 1e-300)):
+                return None
+        return mult, add
+    except Exception:  # noqa: BLE001
+        return None
+
+
 class CachedSurrogateLikelihood:
     """Picklable callable: GP factorised once, then mean(-and-variance) predictions per call
     (alabi/core.py:28-122)."""
@@ -741,9 +765,17 @@ class SurrogateModel(object):
                                       "its kernel; custom like_fn / prior_fn callables are not supported")
         if not hasattr(self, "gp"):
             raise NameError("GP has not been trained")
-        probe = self.bounds.T.astype(np.float64)
-        if not (_is_identity(self.theta_scaler, probe) and _is_identity(self.y_scaler, np.array([[-1.5], [2.5]]))):
-            raise NotImplementedError("run_emcee on the GPU needs identity theta/y scalers (no_scaler) for now")
+        # Affine scalers (no_scaler, MinMaxScaler, StandardScaler, ...) run on the GPU: the ensemble moves in the scaled
+        # coordinates the GP was trained in (the stretch move is affine-invariant, the uniform box maps to self._bounds) and
+        # the log-probability is y_scaler^-1 of the GP mean, an affine map folded into the kernel.  Anything else is rejected.
+        t_aff = _affine_map(self.theta_scaler.transform, self.bounds)
+        y_lo, y_hi = float(np.min(self._y)), float(np.max(self._y))
+        y_aff = _affine_map(self.y_scaler.inverse_transform, np.array([[y_lo - 1.0, y_hi + 1.0]]))
+        if t_aff is None or y_aff is None or not (y_aff[0][0] > 0):
+            raise NotImplementedError("run_emcee on the GPU needs affine theta / y scalers (no_scaler, MinMaxScaler, "
+                                      "StandardScaler, ...)")
+        t_mult, t_add = t_aff                      # scaled = t_mult * theta + t_add, per dimension
+        logp_affine = (float(y_aff[0][0]), float(y_aff[1][0]))
         self.like_fn_name = "surrogate"
         self.like_fn = self.surrogate_log_likelihood
         self.prior_fn = partial(ut.lnprior_uniform, bounds=self.bounds)
@@ -754,6 +786,8 @@ class SurrogateModel(object):
         if len(self.training_results["iteration"]) > 0:
             self.eval_gp_at_iteration(-1)   # makes self.gp carry the latest hyper-parameters / data
         p0 = ut.prior_sampler(nsample=self.nwalkers, bounds=self.bounds, sampler="uniform", random_state=self._seed())
+        p0 = p0 * t_mult + t_add                   # walkers live in scaled coordinates
+        to_theta = lambda c: (np.asarray(c) - t_add) / t_mult  # noqa: E731
         if self.verbose:
             print(f"Running emcee-style ensemble on the GPU with {self.nwalkers} walkers for {self.nsteps} steps...")
         all_chains, all_times, accumulated, run_number = [], [], 0, 1
@@ -761,13 +795,14 @@ class SurrogateModel(object):
         kw.setdefault("seed", self._seed())
         while True:
             t0 = time.time()
-            self.emcee_sampler = EnsembleSampler(self.nwalkers, self.ndim, self.gp, self._y, self._bounds, **kw)
+            self.emcee_sampler = EnsembleSampler(self.nwalkers, self.ndim, self.gp, self._y, self._bounds,
+                                                 logp_affine=logp_affine, **kw)
             self.emcee_sampler.run_mcmc(p0, self.nsteps, **run_kwargs)
             all_times.append(time.time() - t0)
             cur_iburn, cur_ithin = mcmc_utils.estimate_burnin(self.emcee_sampler, verbose=self.verbose)
             cur_burn = burn if burn is not None else cur_iburn
             cur_thin = thin if thin is not None else cur_ithin
-            cur = self.emcee_sampler.get_chain(discard=cur_burn, thin=cur_thin, flat=True)
+            cur = to_theta(self.emcee_sampler.get_chain(discard=cur_burn, thin=cur_thin, flat=True))
             all_chains.append(cur)
             accumulated += cur.shape[0]
             if self.verbose and min_ess > 0:
@@ -781,7 +816,7 @@ class SurrogateModel(object):
             p0 = self.emcee_sampler.get_last_sample().coords
             kw["seed"] = self._seed()
         self.emcee_samples = np.vstack(all_chains) if len(all_chains) > 1 else all_chains[0]
-        self.emcee_samples_full = self.emcee_sampler.get_chain()
+        self.emcee_samples_full = to_theta(self.emcee_sampler.get_chain())
         self.iburn, self.ithin = cur_iburn, cur_ithin
         self.burn, self.thin = cur_burn, cur_thin
         self.emcee_runtime = sum(all_times)

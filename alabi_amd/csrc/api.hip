@@ -449,6 +449,13 @@ int alabi_ens_destroy(alabi_ens* e) {
     return ALABI_OK;
 }
 
+int alabi_ens_set_logp_affine(alabi_ens* e, double scale, double shift) {
+    if (!e || !(scale > 0.0) || !std::isfinite(scale) || !std::isfinite(shift)) return ALABI_BAD_ARGUMENT;
+    e->lp_scale = scale; e->lp_shift = shift;
+    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }   // captured launches carry the old values
+    return ALABI_OK;
+}
+
 int alabi_ens_set_stream(alabi_ens* e, int enabled) {
     if (!e) return ALABI_BAD_ARGUMENT;
     if (enabled && !(e->hist && e->err)) return ALABI_BAD_ARGUMENT;
@@ -490,7 +497,8 @@ static HalfArgs base_args(alabi_ens* e, double* coords, double* logp) {
     alabi_gp* gp = e->gp;
     h.coords = coords; h.logp = logp; h.consts = e->consts;
     h.Xt = gp->Xt; h.alpha = gp->alpha; h.Npad = gp->Npad;
-    h.amp = std::exp(gp->log_amp); h.mean = gp->mean; h.kf = gp->kf;
+    // the affine map of the log-probability folds into the amplitude and the mean: c (amp s + m) + e = (c amp) s + (c m + e)
+    h.amp = e->lp_scale * std::exp(gp->log_amp); h.mean = std::fma(e->lp_scale, gp->mean, e->lp_shift); h.kf = gp->kf;
     h.W = e->W; h.d = e->d; h.n0 = (e->W + 1) / 2;
     h.thin_by = 1; h.run_state = e->run_state;
     return h;

@@ -107,6 +107,7 @@ struct alabi_ens {
     alabi_gp* gp = nullptr;
     int W = 0, d = 0, E = 1;
     int threads = 1024;       // workgroup size of the half-step kernel
+    double lp_scale = 1.0, lp_shift = 0.0;   // log-probability = lp_scale * GP mean + lp_shift inside the box (y scaler)
     unsigned long long seed = 0;
     double lo[ALABI_MAX_DIM], hi[ALABI_MAX_DIM];
     double* consts = nullptr; // device [3][ALABI_MAX_DIM]: inv_len, lo, hi

@@ -786,7 +786,7 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
     a.n_accept = reinterpret_cast<unsigned long long*>(n_accept); a.run_state = e->run_state;
     a.K = K; a.W = e->W; a.n0 = n0; a.d = e->d; a.Npad = gp->Npad; a.thin_by = thin_by; a.spin_limit = 1 << 20;
     if (const char* env = getenv("ALABI_ENS_SPIN_LIMIT")) { const int v = atoi(env); if (v > 0) a.spin_limit = v; }   // tests: force a time-out
-    a.amp = exp(gp->log_amp); a.mean = gp->mean; a.kf = gp->kf;
+    a.amp = e->lp_scale * exp(gp->log_amp); a.mean = fma(e->lp_scale, gp->mean, e->lp_shift); a.kf = gp->kf;
     const int db = dim_bucket(e->d);
     // lanes x pairs-per-lane cover Npad/2 point pairs; the launch-per-half-step kernel's lane -> point map (and so its
     // summation order) is reproduced exactly because both run with e->threads compute lanes.
@@ -863,8 +863,8 @@ int launch_ens_lnprob(alabi_ens* e, const double* coords, int nwalkers, double* 
     const int db = dim_bucket(e->d);
     alabi_gp* gp = e->gp;
     ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(ens_lnprob_kernel<D>, dim3(nwalkers), dim3(e->threads), 0, s, coords, e->d,
-                                              gp->Xt, gp->alpha, gp->Npad, exp(gp->log_amp), gp->mean, gp->kf, e->consts,
-                                              logp));
+                                              gp->Xt, gp->alpha, gp->Npad, e->lp_scale * exp(gp->log_amp),
+                                              fma(e->lp_scale, gp->mean, e->lp_shift), gp->kf, e->consts, logp));
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

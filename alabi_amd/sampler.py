@@ -38,9 +38,10 @@ class State:
 
 class EnsembleSampler:
     def __init__(self, nwalkers, ndim, gp, y, bounds, seed=None, a=2.0, pool=None, live_dangerously=False,
-                 n_ensembles=1, **unused):
+                 n_ensembles=1, logp_affine=(1.0, 0.0), **unused):
         """``n_ensembles`` > 1 runs that many INDEPENDENT ensembles of ``nwalkers`` walkers in the same kernel
-        launches (rows [e*nwalkers, (e+1)*nwalkers) of every array belong to ensemble e)."""
+        launches (rows [e*nwalkers, (e+1)*nwalkers) of every array belong to ensemble e).
+        ``logp_affine=(scale, shift)``: log-probability = scale * GP mean + shift inside the box (an affine y scaler)."""
         if not isinstance(gp, HipGP):
             raise TypeError("EnsembleSampler needs the HipGP surrogate (the log-probability is fused into the kernel)")
         self.nwalkers = int(nwalkers)
@@ -56,6 +57,7 @@ class EnsembleSampler:
         self._y = y
         self.bounds = np.ascontiguousarray(np.asarray(bounds, dtype=np.float64).reshape(self.ndim, 2))
         self.a = float(a)
+        self.logp_affine = (float(logp_affine[0]), float(logp_affine[1]))
         if seed is None:
             seed = int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).view(np.uint64)[0])
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -82,6 +84,9 @@ class EnsembleSampler:
         st = _lib.lib().alabi_ens_create(h, self.nwalkers, self.ndim, self.n_ensembles,
                                          _lib.host_doubles(self.bounds.ravel()), C.c_ulonglong(self.seed), C.byref(e))
         _lib.check(st, "alabi_ens_create")
+        if self.logp_affine != (1.0, 0.0):
+            _lib.check(_lib.lib().alabi_ens_set_logp_affine(e, self.logp_affine[0], self.logp_affine[1]),
+                       "alabi_ens_set_logp_affine")
         self._ens = e
         self._ens_gp_handle = C.c_void_p(h.value)
 

@@ -124,6 +124,12 @@ int alabi_utility_eval(int algo, const double* Xs, long long M, int d, const dou
 int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* bounds,
                      unsigned long long seed, alabi_ens** out);
 int alabi_ens_destroy(alabi_ens* ens);
+/* Log-probability inside the box = scale * (GP mean) + shift.  Default (1, 0) is the reference's lnprob with identity
+ * scalers; an affine y_scaler (alabi/core.py:1483-1502: y = y_scaler.inverse_transform(gp.predict(...))) sets its slope and
+ * offset here, an affine theta_scaler is absorbed by running the ensemble in scaled coordinates (the stretch move is
+ * affine-invariant).  scale > 0.  Affects alabi_ens_lnprob / run / half_step from the next call on. */
+int alabi_ens_set_logp_affine(alabi_ens* ens, double scale, double shift);
+
 /* Enable / disable the persistent dataflow kernel for alabi_ens_run on this handle (default: enabled when the
  * ensemble fits one workgroup per CU).  Returns ALABI_BAD_ARGUMENT when enabling is impossible. */
 int alabi_ens_set_stream(alabi_ens* ens, int enabled);
