@@ -760,9 +760,25 @@ class SurrogateModel(object):
 
         Accelerated case (the reference's default): like_fn=None (GP surrogate) and prior_fn=None (uniform
         prior on self.bounds).  Arbitrary Python callables cannot run inside the kernel and are rejected."""
-        if like_fn is not None or prior_fn is not None:
-            raise NotImplementedError("the HIP ensemble sampler fuses the surrogate mean + uniform-box prior into "
-                                      "its kernel; custom like_fn / prior_fn callables are not supported")
+        # prior_fn: None (uniform box) or functools.partial(lnprior_normal, bounds=..., data=...) -- the two priors the
+        # reference ships (utility.py:218, :370); both are fused into the kernel.  Other callables cannot run there.
+        prior_bounds, prior_data = None, None
+        if prior_fn is not None:
+            f = getattr(prior_fn, "func", None)
+            kwp = dict(getattr(prior_fn, "keywords", None) or {})
+            argp = tuple(getattr(prior_fn, "args", ()) or ())
+            name = getattr(f, "__name__", "")
+            if name == "lnprior_uniform" and ("bounds" in kwp or len(argp) >= 1):
+                prior_bounds = kwp.get("bounds", argp[0] if argp else None)
+            elif name == "lnprior_normal" and (("bounds" in kwp and "data" in kwp) or len(argp) >= 2):
+                prior_bounds = kwp.get("bounds", argp[0] if argp else None)
+                prior_data = kwp.get("data", argp[1] if len(argp) > 1 else None)
+            else:
+                raise NotImplementedError("the HIP ensemble sampler fuses the prior into its kernel: prior_fn must be None, "
+                                          "partial(lnprior_uniform, bounds=...) or partial(lnprior_normal, bounds=..., data=...)")
+        if like_fn is not None:
+            raise NotImplementedError("the HIP ensemble sampler fuses the surrogate mean into its kernel; a custom like_fn "
+                                      "callable is not supported")
         if not hasattr(self, "gp"):
             raise NameError("GP has not been trained")
         # Affine scalers (no_scaler, MinMaxScaler, StandardScaler, ...) run on the GPU: the ensemble moves in the scaled
@@ -776,16 +792,26 @@ class SurrogateModel(object):
                                       "StandardScaler, ...)")
         t_mult, t_add = t_aff                      # scaled = t_mult * theta + t_add, per dimension
         logp_affine = (float(y_aff[0][0]), float(y_aff[1][0]))
+        box = self.bounds if prior_bounds is None else np.asarray(prior_bounds, dtype=np.float64).reshape(self.ndim, 2)
+        _box = np.sort(box * t_mult[:, None] + t_add[:, None], axis=1)          # the prior box in scaled coordinates
+        normal_prior = None
+        if prior_data is not None:
+            pm = np.array([np.nan if dd[0] is None else float(dd[0]) for dd in prior_data])
+            ps = np.array([np.nan if dd[0] is None else float(dd[1]) for dd in prior_data])
+            # N(m, s) on theta_k is N(mult m + add, |mult| s) on the scaled coordinate; the density stays the theta-space one,
+            # so log|mult| per normal coordinate goes back into the log-probability through the constant shift
+            normal_prior = (pm * t_mult + t_add, ps * np.abs(t_mult))
+            logp_affine = (logp_affine[0], logp_affine[1] + float(np.sum(np.log(np.abs(t_mult[np.isfinite(pm)])))))
         self.like_fn_name = "surrogate"
         self.like_fn = self.surrogate_log_likelihood
-        self.prior_fn = partial(ut.lnprior_uniform, bounds=self.bounds)
+        self.prior_fn = partial(ut.lnprior_uniform, bounds=self.bounds) if prior_fn is None else prior_fn
         self.prior_fn_comment = ("Default uniform prior. \nPrior function: ut.prior_fn_uniform\n"
                                  f"\twith bounds {self.bounds}") if prior_fn_comment is None else prior_fn_comment
         self.nwalkers = int(10 * self.ndim) if nwalkers is None else int(nwalkers)
         self.nsteps = int(nsteps)
         if len(self.training_results["iteration"]) > 0:
             self.eval_gp_at_iteration(-1)   # makes self.gp carry the latest hyper-parameters / data
-        p0 = ut.prior_sampler(nsample=self.nwalkers, bounds=self.bounds, sampler="uniform", random_state=self._seed())
+        p0 = ut.prior_sampler(nsample=self.nwalkers, bounds=box, sampler="uniform", random_state=self._seed())
         p0 = p0 * t_mult + t_add                   # walkers live in scaled coordinates
         to_theta = lambda c: (np.asarray(c) - t_add) / t_mult  # noqa: E731
         if self.verbose:
@@ -795,8 +821,8 @@ class SurrogateModel(object):
         kw.setdefault("seed", self._seed())
         while True:
             t0 = time.time()
-            self.emcee_sampler = EnsembleSampler(self.nwalkers, self.ndim, self.gp, self._y, self._bounds,
-                                                 logp_affine=logp_affine, **kw)
+            self.emcee_sampler = EnsembleSampler(self.nwalkers, self.ndim, self.gp, self._y, _box,
+                                                 logp_affine=logp_affine, normal_prior=normal_prior, **kw)
             self.emcee_sampler.run_mcmc(p0, self.nsteps, **run_kwargs)
             all_times.append(time.time() - t0)
             cur_iburn, cur_ithin = mcmc_utils.estimate_burnin(self.emcee_sampler, verbose=self.verbose)

@@ -411,7 +411,7 @@ int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* 
     if (err == hipSuccess) err = hipMalloc(&b.u_acc, n * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&b.packed, 4 * n * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMalloc(&e->run_state, 4 * sizeof(long long));
-    if (err == hipSuccess) err = hipMalloc(&e->consts, 3 * ALABI_MAX_DIM * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc(&e->consts, 5 * ALABI_MAX_DIM * sizeof(double));
     // persistent dataflow path: one workgroup per list position, all co-resident (at most one per CU)
     {
         int dev = 0, n_cu = 0;
@@ -449,6 +449,23 @@ int alabi_ens_destroy(alabi_ens* e) {
     return ALABI_OK;
 }
 
+int alabi_ens_set_normal_prior(alabi_ens* e, const double* mean, const double* std) {
+    if (!e || !mean || !std) return ALABI_BAD_ARGUMENT;
+    e->has_prior = 0; e->prior_const = 0.0;
+    for (int k = 0; k < ALABI_MAX_DIM; ++k) { e->prior_mean[k] = 0.0; e->prior_istd[k] = 0.0; }
+    for (int k = 0; k < e->d; ++k) {
+        if (std::isfinite(mean[k]) && std::isfinite(std[k]) && std[k] > 0.0) {
+            e->prior_mean[k] = mean[k];
+            e->prior_istd[k] = 1.0 / std[k];
+            e->prior_const += -std::log(std[k]) - 0.9189385332046727;   // -log(std) - log(2 pi) / 2, as norm.logpdf
+            e->has_prior = 1;
+        }
+    }
+    e->consts_gen = -1;                                                  // re-upload
+    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+    return ALABI_OK;
+}
+
 int alabi_ens_set_logp_affine(alabi_ens* e, double scale, double shift) {
     if (!e || !(scale > 0.0) || !std::isfinite(scale) || !std::isfinite(shift)) return ALABI_BAD_ARGUMENT;
     e->lp_scale = scale; e->lp_shift = shift;
@@ -472,11 +489,13 @@ int alabi_ens_last_path(alabi_ens* e, int* path) {
 // (inv_len, lo, hi) live in device memory; refreshed whenever the GP's hyper-parameters changed.
 static int sync_consts(alabi_ens* e, hipStream_t s) {
     if (e->consts_gen == e->gp->gen) return ALABI_OK;
-    double host[3 * ALABI_MAX_DIM];
+    double host[5 * ALABI_MAX_DIM];
     for (int k = 0; k < ALABI_MAX_DIM; ++k) {
         host[k] = e->gp->inv_len.v[k];
         host[ALABI_MAX_DIM + k] = e->lo[k];
         host[2 * ALABI_MAX_DIM + k] = e->hi[k];
+        host[3 * ALABI_MAX_DIM + k] = e->prior_mean[k];
+        host[4 * ALABI_MAX_DIM + k] = e->prior_istd[k];
     }
     ALABI_HIP_CHECK(hipMemcpyAsync(e->consts, host, sizeof(host), hipMemcpyHostToDevice, s));
     ALABI_HIP_CHECK(hipStreamSynchronize(s));  // `host` is a stack buffer
@@ -501,6 +520,7 @@ static HalfArgs base_args(alabi_ens* e, double* coords, double* logp) {
     h.amp = e->lp_scale * std::exp(gp->log_amp); h.mean = std::fma(e->lp_scale, gp->mean, e->lp_shift); h.kf = gp->kf;
     h.W = e->W; h.d = e->d; h.n0 = (e->W + 1) / 2;
     h.thin_by = 1; h.run_state = e->run_state;
+    h.has_prior = e->has_prior; h.prior_const = e->prior_const;
     return h;
 }
 

@@ -108,6 +108,10 @@ struct alabi_ens {
     int W = 0, d = 0, E = 1;
     int threads = 1024;       // workgroup size of the half-step kernel
     double lp_scale = 1.0, lp_shift = 0.0;   // log-probability = lp_scale * GP mean + lp_shift inside the box (y scaler)
+    // independent normal priors on selected coordinates (lnprior_normal): mean, 1 / std (0 = none), sum of the constants
+    double prior_mean[ALABI_MAX_DIM] = {0}, prior_istd[ALABI_MAX_DIM] = {0};
+    double prior_const = 0.0;
+    int has_prior = 0;
     unsigned long long seed = 0;
     double lo[ALABI_MAX_DIM], hi[ALABI_MAX_DIM];
     double* consts = nullptr; // device [3][ALABI_MAX_DIM]: inv_len, lo, hi
@@ -170,7 +174,7 @@ struct HalfArgs {
     double* coords;              // [E*W,d] in/out
     double* logp;                // [E*W] in/out
     DrawBuffers rec;             // already offset to the step
-    const double* consts;        // device [3][ALABI_MAX_DIM]: inv_len, lo, hi
+    const double* consts;        // device [5][ALABI_MAX_DIM]: inv_len, lo, hi, prior mean, prior 1 / std
     const double* Xt;            // [D,Npad]
     const double* alpha;         // [Npad]
     double* chain;               // [nstore,E*W,d] or null
@@ -179,6 +183,8 @@ struct HalfArgs {
     const long long* run_state;  // [0] chunk's first global step, [1] steps done before the chunk
     int n0, W, d, Npad, split, part_begin, local_t, thin_by;
     int count;                   // proposals in this launch (several per workgroup in ens_half_multi_kernel)
+    int has_prior;               // consts rows 3 / 4 hold prior mean and 1 / std
+    double prior_const;
     double amp, mean;
     KernelFn kf;
 };

@@ -155,6 +155,14 @@ ens_prep_kernel(const int* __restrict__ order, int n0, int W, const double* __re
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+// Normal-prior term of coordinate `lane` (< d) of a proposal, summed over the wave: lanes >= d contribute 0.
+// consts rows 3 / 4: prior mean, 1 / std (0 where there is no normal prior).  Result valid in every lane.
+__device__ inline double normal_prior_sum(const double* pmean, const double* pistd, int lane, int d, double x) {
+    double t = 0.0;
+    if (lane < d) { t = (x - pmean[lane]) * pistd[lane]; t = -0.5 * t * t; }
+    return lane_bcast(wave_sum_dpp(t), 63);
+}
+
 template <int D, bool GENERIC>
 __global__ void __launch_bounds__(1024)
 ens_half_kernel(HalfArgs p) {
@@ -235,6 +243,8 @@ ens_half_kernel(HalfArgs p) {
         part = wave_sum_dpp(part);   // fixed order: bit-reproducible
         const double s = lane_bcast(part, 63);
         lp_new = fma(p.amp, s, p.mean);
+        if (p.has_prior)
+            lp_new += normal_prior_sum(p.consts + 3 * ALABI_MAX_DIM, p.consts + 4 * ALABI_MAX_DIM, tid, p.d, q_s[tid]) + p.prior_const;
     } else if (tid >= 64) {
         return;
     }
@@ -358,6 +368,9 @@ ens_half_multi_kernel(HalfArgs p) {
             double part = (tid < nw) ? scratch[pp][tid] : 0.0;
             part = wave_sum_dpp(part);
             lp_new = fma(p.amp, lane_bcast(part, 63), p.mean);
+            if (p.has_prior)
+                lp_new += normal_prior_sum(p.consts + 3 * ALABI_MAX_DIM, p.consts + 4 * ALABI_MAX_DIM, tid, p.d, q_s[pp][tid]) +
+                          p.prior_const;
         }
         const double lp_old = lpold_s[pp];
         const int acc_flag = (lnfac_s[pp] + lp_new - lp_old > lnu_s[pp]) ? 1 : 0;
@@ -386,23 +399,31 @@ template <int D>
 __global__ void __launch_bounds__(1024)
 ens_lnprob_kernel(const double* __restrict__ coords, int d, const double* __restrict__ Xt,
                   const double* __restrict__ alpha, int Npad, double amp, double mean, KernelFn kf,
-                  const double* __restrict__ consts, double* __restrict__ logp) {
+                  const double* __restrict__ consts, int has_prior, double prior_const, double* __restrict__ logp) {
     __shared__ double qs_s[ALABI_MAX_DIM];
     __shared__ double scratch[16];
+    __shared__ double prior_s;
     const int tid = threadIdx.x, w = blockIdx.x;
     int ok = 1;
+    double qraw = 0.0;
     if (tid < D) {
         double qv = 0.0;
         if (tid < d) {
             qv = coords[(size_t)w * d + tid];
+            qraw = qv;
             ok = (qv > consts[ALABI_MAX_DIM + tid]) && (qv < consts[2 * ALABI_MAX_DIM + tid]);
             qv *= consts[tid];
         }
         qs_s[tid] = qv;
     }
+    if (tid < 64) {
+        const double pr = has_prior ? normal_prior_sum(consts + 3 * ALABI_MAX_DIM, consts + 4 * ALABI_MAX_DIM, tid, d, qraw) + prior_const
+                                    : 0.0;
+        if (tid == 0) prior_s = pr;
+    }
     const int inb = __syncthreads_and(ok);
     double lp = -INFINITY;
-    if (inb) lp = fma(amp, gp_kernel_dot_block<D>(Xt, alpha, Npad, qs_s, scratch, kf), mean);
+    if (inb) lp = fma(amp, gp_kernel_dot_block<D>(Xt, alpha, Npad, qs_s, scratch, kf), mean) + prior_s;
     if (tid == 0) logp[w] = lp;
 }
 
@@ -438,8 +459,8 @@ struct StreamArgs {
     double* chain_logp;
     unsigned long long* n_accept;
     const long long* run_state;
-    int K, W, n0, d, Npad, thin_by, spin_limit;
-    double amp, mean;
+    int K, W, n0, d, Npad, thin_by, spin_limit, has_prior;
+    double amp, mean, prior_const;
     KernelFn kf;
 };
 
@@ -483,7 +504,7 @@ ens_stream_kernel(StreamArgs p) {
     __shared__ __attribute__((aligned(16))) double scratch[2][16];   // wave partials, by proposal parity
     __shared__ unsigned long long rec_s[4][4];                       // proposal-record ring (last wave -> wave 0)
     __shared__ __attribute__((aligned(16))) double qs_s[2][ALABI_MAX_DIM];   // scaled proposal, by proposal parity
-    __shared__ double consts_s[3][ALABI_MAX_DIM];                    // [0] 1/length scale, [1] lower bound, [2] upper bound
+    __shared__ double consts_s[5][ALABI_MAX_DIM];                    // 1/length scale, lower, upper bound, prior mean, prior 1/std
     __shared__ int ctl_s[2][2];                                      // [parity][0] proposal inside the box; [0][1] abort
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int TC = blockDim.x - 128, nwc = TC >> 6;
@@ -510,6 +531,8 @@ ens_stream_kernel(StreamArgs p) {
         consts_s[0][tid] = (tid < p.d) ? p.consts[tid] : 0.0;
         consts_s[1][tid] = (tid < p.d) ? p.consts[ALABI_MAX_DIM + tid] : 0.0;
         consts_s[2][tid] = (tid < p.d) ? p.consts[2 * ALABI_MAX_DIM + tid] : 0.0;
+        consts_s[3][tid] = (tid < p.d) ? p.consts[3 * ALABI_MAX_DIM + tid] : 0.0;
+        consts_s[4][tid] = (tid < p.d) ? p.consts[4 * ALABI_MAX_DIM + tid] : 0.0;
     }
     if (tid < 32) scratch[tid >> 4][tid & 15] = 0.0;
     if (tid < 4) ctl_s[tid >> 1][tid & 1] = 0;
@@ -651,7 +674,9 @@ ens_stream_kernel(StreamArgs p) {
             const double wsum = wave_sum_dpp(acc);
             if (lane == 63) scratch[par][wv - 1] = wsum;
         }
+        double prior_q = 0.0;                         // normal-prior term of this proposal (0.0 adds exactly nothing)
         if (comm) {                                   // idle until barrier B: prepare the store and the next proposal
+            if (p.has_prior) prior_q = normal_prior_sum(consts_s[3], consts_s[4], lane, p.d, qv) + p.prior_const;
             out_row = p.hist + ((size_t)(t + 1) * WT + w) * row + lane;
             if (t2 < p.K) decode_next(item + 1, t2, s2);
         }
@@ -667,7 +692,7 @@ ens_stream_kernel(StreamArgs p) {
         if (ctl_s[0][1]) return;
         if (comm) {
             double lp_new = -INFINITY;
-            if (all_in) lp_new = fma(p.amp, wave_partials_tree(scratch[par], nwc), p.mean);
+            if (all_in) lp_new = fma(p.amp, wave_partials_tree(scratch[par], nwc), p.mean) + prior_q;
             const double lp_old = lane_bcast(sv, p.d);                // lane d loaded logp
             const int acc_flag = (lnfac + lp_new - lp_old > lnu) ? 1 : 0;
             // new row of the walker: lanes k < d coordinates, lane d logp, lane d+1 the acceptance flag
@@ -787,6 +812,7 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
     a.K = K; a.W = e->W; a.n0 = n0; a.d = e->d; a.Npad = gp->Npad; a.thin_by = thin_by; a.spin_limit = 1 << 20;
     if (const char* env = getenv("ALABI_ENS_SPIN_LIMIT")) { const int v = atoi(env); if (v > 0) a.spin_limit = v; }   // tests: force a time-out
     a.amp = e->lp_scale * exp(gp->log_amp); a.mean = fma(e->lp_scale, gp->mean, e->lp_shift); a.kf = gp->kf;
+    a.has_prior = e->has_prior; a.prior_const = e->prior_const;
     const int db = dim_bucket(e->d);
     // lanes x pairs-per-lane cover Npad/2 point pairs; the launch-per-half-step kernel's lane -> point map (and so its
     // summation order) is reproduced exactly because both run with e->threads compute lanes.
@@ -864,7 +890,8 @@ int launch_ens_lnprob(alabi_ens* e, const double* coords, int nwalkers, double* 
     alabi_gp* gp = e->gp;
     ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(ens_lnprob_kernel<D>, dim3(nwalkers), dim3(e->threads), 0, s, coords, e->d,
                                               gp->Xt, gp->alpha, gp->Npad, e->lp_scale * exp(gp->log_amp),
-                                              fma(e->lp_scale, gp->mean, e->lp_shift), gp->kf, e->consts, logp));
+                                              fma(e->lp_scale, gp->mean, e->lp_shift), gp->kf, e->consts, e->has_prior,
+                                              e->prior_const, logp));
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

@@ -38,10 +38,12 @@ class State:
 
 class EnsembleSampler:
     def __init__(self, nwalkers, ndim, gp, y, bounds, seed=None, a=2.0, pool=None, live_dangerously=False,
-                 n_ensembles=1, logp_affine=(1.0, 0.0), **unused):
+                 n_ensembles=1, logp_affine=(1.0, 0.0), normal_prior=None, **unused):
         """``n_ensembles`` > 1 runs that many INDEPENDENT ensembles of ``nwalkers`` walkers in the same kernel
         launches (rows [e*nwalkers, (e+1)*nwalkers) of every array belong to ensemble e).
-        ``logp_affine=(scale, shift)``: log-probability = scale * GP mean + shift inside the box (an affine y scaler)."""
+        ``logp_affine=(scale, shift)``: log-probability = scale * GP mean + shift inside the box (an affine y scaler).
+        ``normal_prior=(mean[d], std[d])``: independent normal priors on top of the box (NaN / non-positive std = none on
+        that coordinate), the reference's ``lnprior_normal``."""
         if not isinstance(gp, HipGP):
             raise TypeError("EnsembleSampler needs the HipGP surrogate (the log-probability is fused into the kernel)")
         self.nwalkers = int(nwalkers)
@@ -58,6 +60,11 @@ class EnsembleSampler:
         self.bounds = np.ascontiguousarray(np.asarray(bounds, dtype=np.float64).reshape(self.ndim, 2))
         self.a = float(a)
         self.logp_affine = (float(logp_affine[0]), float(logp_affine[1]))
+        self.normal_prior = None
+        if normal_prior is not None:
+            m = np.ascontiguousarray(np.asarray(normal_prior[0], dtype=np.float64).reshape(self.ndim))
+            sd = np.ascontiguousarray(np.asarray(normal_prior[1], dtype=np.float64).reshape(self.ndim))
+            self.normal_prior = (m, sd)
         if seed is None:
             seed = int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).view(np.uint64)[0])
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -87,6 +94,10 @@ class EnsembleSampler:
         if self.logp_affine != (1.0, 0.0):
             _lib.check(_lib.lib().alabi_ens_set_logp_affine(e, self.logp_affine[0], self.logp_affine[1]),
                        "alabi_ens_set_logp_affine")
+        if self.normal_prior is not None:
+            _lib.check(_lib.lib().alabi_ens_set_normal_prior(e, _lib.host_doubles(self.normal_prior[0]),
+                                                             _lib.host_doubles(self.normal_prior[1])),
+                       "alabi_ens_set_normal_prior")
         self._ens = e
         self._ens_gp_handle = C.c_void_p(h.value)
 

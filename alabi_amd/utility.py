@@ -24,7 +24,7 @@ from sklearn.preprocessing import FunctionTransformer
 from . import _lib
 
 __all__ = ["agp_utility", "bape_utility", "jones_utility", "assign_utility", "minimize_objective",
-           "prior_sampler", "lnprior_uniform", "prior_transform_uniform", "logsubexp",
+           "prior_sampler", "lnprior_uniform", "lnprior_normal", "prior_transform_uniform", "logsubexp",
            "NewFunctionTransformer", "nlog_scaler", "log_scaler", "no_scaler",
            "utility_scan", "utility_eval_device"]
 
@@ -99,6 +99,16 @@ def lnprior_uniform(x, bounds):
     for i in range(ndim):
         inside = inside and bool((x[i] > b[i][0]) and (x[i] < b[i][1]))
     return 0.0 if inside else -np.inf
+
+
+def lnprior_normal(x, bounds, data):
+    """Uniform box plus independent normal priors on the coordinates whose ``data[i] = (mean, std)`` is not
+    ``(None, None)`` (utility.py:370-378)."""
+    lnp = lnprior_uniform(x, bounds)
+    for ii in range(len(x)):
+        if data[ii][0] is not None:
+            lnp += norm.logpdf(x[ii], data[ii][0], data[ii][1])
+    return lnp
 
 
 def prior_transform_uniform(theta, bounds):

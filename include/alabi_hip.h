@@ -124,6 +124,12 @@ int alabi_utility_eval(int algo, const double* Xs, long long M, int d, const dou
 int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* bounds,
                      unsigned long long seed, alabi_ens** out);
 int alabi_ens_destroy(alabi_ens* ens);
+/* Independent normal priors on selected coordinates on top of the uniform box: the reference's lnprior_normal
+ * (alabi/utility.py:370-378; passed to run_emcee as prior_fn, alabi/core.py:2108).  mean[d], std[d] on the HOST in the
+ * sampler's coordinates; a non-finite mean or std <= 0 means "no normal prior on this coordinate".  Adds
+ * sum_k norm.logpdf(x_k, mean_k, std_k) to the log-probability.  Takes effect from the next call on. */
+int alabi_ens_set_normal_prior(alabi_ens* ens, const double* mean, const double* std);
+
 /* Log-probability inside the box = scale * (GP mean) + shift.  Default (1, 0) is the reference's lnprob with identity
  * scalers; an affine y_scaler (alabi/core.py:1483-1502: y = y_scaler.inverse_transform(gp.predict(...))) sets its slope and
  * offset here, an affine theta_scaler is absorbed by running the ensemble in scaled coordinates (the stretch move is

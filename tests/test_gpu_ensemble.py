@@ -247,3 +247,47 @@ def test_multi_proposal_half_step_bit_identical(W, E, monkeypatch):
         out[multi] = (s.get_chain(), s.get_log_prob(), s.acceptance_fraction)
     for a, b in zip(out["0"], out["1"]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("stream", ["1", "0"])
+def test_normal_prior_and_logp_affine_against_oracle(stream, monkeypatch):
+    """lnprior_normal on two of four coordinates plus an affine log-probability map: both ensemble paths (and the multi-proposal
+    kernel through E = 12) must follow the oracle run step for step."""
+    from scipy.stats import norm
+    from alabi_amd import EnsembleSampler, HipGP
+    from oracle import stretch_oracle as so
+    from oracle.gp_oracle import OracleGP
+    X, y, h = make_problem(220, 4, 77, log_wn=-9.0)
+    g = HipGP(4, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+    o = OracleGP(4, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X)
+    bounds = np.array([[-3.0, 3.0]] * 4)
+    pm = np.array([0.4, np.nan, -0.8, np.nan]); ps = np.array([0.7, np.nan, 1.3, np.nan])
+    c, e0 = 2.5, -3.0
+
+    def lnp(q):
+        inside = np.all((q > -3) & (q < 3), axis=1)
+        out = np.full(len(q), -np.inf)
+        if inside.any():
+            v = c * o.predict(y, q[inside]) + e0
+            for k in (0, 2):
+                v = v + norm.logpdf(q[inside][:, k], pm[k], ps[k])
+            out[inside] = v
+        return out
+
+    monkeypatch.setenv("ALABI_ENS_STREAM", stream)
+    W = 24
+    p0 = np.random.RandomState(3).uniform(-2, 2, (W, 4))
+    ref = so.run_ensemble(p0, 150, lnp, seed=13)
+    s = EnsembleSampler(W, 4, g, y, bounds, seed=13, logp_affine=(c, e0), normal_prior=(pm, ps))
+    s.run_mcmc(p0, 150)
+    assert np.max(np.abs(s.get_chain() - ref[0])) < 1e-7
+    assert np.max(np.abs(s.get_log_prob() - ref[1])) < 1e-7 * (np.max(np.abs(ref[1])) + 1)
+    np.testing.assert_array_equal(np.rint(s.acceptance_fraction * 150).astype(np.int64), ref[2])
+    if stream == "0":       # many small ensembles -> several proposals per workgroup
+        E = 12
+        p0e = np.random.RandomState(4).uniform(-2, 2, (W * E, 4))
+        se = EnsembleSampler(W, 4, g, y, bounds, seed=13, n_ensembles=E, logp_affine=(c, e0), normal_prior=(pm, ps))
+        se.run_mcmc(p0e, 40)
+        for k in (0, E - 1):
+            refk = so.run_ensemble(p0e[k * W:(k + 1) * W], 40, lnp, seed=13, id0=k * W)
+            assert np.max(np.abs(se.get_chain()[:, k * W:(k + 1) * W] - refk[0])) < 1e-7

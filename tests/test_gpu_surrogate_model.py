@@ -131,3 +131,29 @@ def test_run_emcee_with_affine_scalers(tmp_path):
     width = width[:, 1] - width[:, 0]
     assert np.all(np.abs(stats["identity"][0] - stats["scaled"][0]) < 0.08 * width)
     assert np.all(np.abs(stats["identity"][1] - stats["scaled"][1]) < 0.08 * width)
+
+
+def test_run_emcee_with_normal_prior(tmp_path):
+    """prior_fn = partial(lnprior_normal, bounds, data) is fused into the kernel: the stored log-probabilities equal
+    surrogate likelihood + prior at the stored points, the posterior mean moves towards the prior mean, anything else raises."""
+    from functools import partial
+    from sklearn.preprocessing import MinMaxScaler
+    from alabi_amd import SurrogateModel, utility as ut
+    from alabi_amd.benchmarks import gaussian_2d
+    b = np.array(gaussian_2d["bounds"], dtype=float)
+    data = [(float(b[0, 0] + 0.7 * (b[0, 1] - b[0, 0])), 0.05 * float(b[0, 1] - b[0, 0])), (None, None)]
+    for ts in (None, MinMaxScaler()):
+        kw = {} if ts is None else {"theta_scaler": ts}
+        sm = SurrogateModel(lnlike_fn=gaussian_2d["fn"], bounds=gaussian_2d["bounds"], savedir=str(tmp_path), verbose=False,
+                            random_state=5, cache=False)
+        sm.init_samples(ntrain=120)
+        sm.init_gp(hyperopt_method="ml", gp_nopt=1, optimizer_kwargs={"maxiter": 10}, **kw)
+        prior = partial(ut.lnprior_normal, bounds=sm.bounds, data=data)
+        sm.run_emcee(prior_fn=prior, nwalkers=20, nsteps=2500, min_ess=100)
+        last = sm.emcee_samples_full[-1]
+        lp = sm.emcee_sampler.get_log_prob()[-1]
+        ref = np.array([float(sm.surrogate_log_likelihood(t)) + float(prior(t)) for t in last])
+        assert np.max(np.abs(lp - ref)) <= 1e-7 * (np.max(np.abs(ref)) + 1)
+        assert abs(sm.emcee_samples[:, 0].mean() - data[0][0]) < 3 * data[0][1]
+    with pytest.raises(NotImplementedError):
+        sm.run_emcee(prior_fn=lambda t: 0.0, nwalkers=20, nsteps=10)
