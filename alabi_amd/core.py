@@ -587,6 +587,10 @@ class SurrogateModel(object):
         vp = self.y_scaler.inverse_transform(_vp.reshape(-1, 1)).flatten()   # reference quirk (core.py:1502)
         return (yp[0], vp[0]) if one else (yp, vp)
 
+    def surrogate_likelihood(self, theta_xs):
+        """Predictive probability (not log) of the GP at theta_xs (core.py:1511-1533)."""
+        return np.exp(self.surrogate_log_likelihood(theta_xs))
+
     def create_cached_surrogate_likelihood(self, iter=-1, return_var=False):
         """Factorise once, return a picklable callable (core.py:1535-1584)."""
         if hasattr(self, "training_results") and len(self.training_results["iteration"]) > 0:
@@ -776,9 +780,11 @@ class SurrogateModel(object):
             else:
                 raise NotImplementedError("the HIP ensemble sampler fuses the prior into its kernel: prior_fn must be None, "
                                           "partial(lnprior_uniform, bounds=...) or partial(lnprior_normal, bounds=..., data=...)")
+        if isinstance(like_fn, str) and like_fn.lower() in ("surrogate", "gp"):
+            like_fn = None                       # the reference's explicit spellings of the default (core.py:2118-2124)
         if like_fn is not None:
-            raise NotImplementedError("the HIP ensemble sampler fuses the surrogate mean into its kernel; a custom like_fn "
-                                      "callable is not supported")
+            raise NotImplementedError("the HIP ensemble sampler fuses the surrogate mean into its kernel; like_fn must be "
+                                      "None / 'surrogate' / 'gp' (the true likelihood or a custom callable cannot run there)")
         if not hasattr(self, "gp"):
             raise NameError("GP has not been trained")
         # Affine scalers (no_scaler, MinMaxScaler, StandardScaler, ...) run on the GPU: the ensemble moves in the scaled
