@@ -219,7 +219,7 @@ int alabi_gp_predict(alabi_gp* gp, const double* Xs, long long M, double* mu, do
         // at most 16 queries: one multiply with the cached L^-1 spread over the block rows instead of 500+ dependent
         // substitution stages (the path of per-point objective calls: utility.py:1030-1163, core.py:1441)
         const char* env = getenv("ALABI_PV_SMALL");
-        if (M <= 16 && gp->Npad >= 256 && gp->d <= 16 && !(env && env[0] == '0')) {
+        if (M <= 16 && gp->Npad >= 256 && gp->d <= 32 && !(env && env[0] == '0')) {
             const bool cached = gp->winv && gp->winv_gen == gp->factor_gen;
             if (cached || gp->Npad <= 2048 || (gp->req_gen == gp->factor_gen && gp->var_requests >= 1)) {
                 (void)want_winv(gp, M);        // count the request

@@ -706,7 +706,7 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
     const int db = dim_bucket(gp->d);
     const long long tiles = (M + 63) / 64;
     const char* legacy = getenv("ALABI_PV_LEGACY");
-    const bool ws_kernel = db <= 16 && !(legacy && legacy[0] == '1');
+    const bool ws_kernel = db <= 32 && !(legacy && legacy[0] == '1');
     const double amp = exp(gp->log_amp);
     if (ws_kernel) {
         // wave-specialised path: every tile owns Npad x 64 doubles of workspace (K* seeds in, V out); queries are processed

@@ -293,7 +293,8 @@ def test_predict_variance_block_row_boundaries(N, w_path, monkeypatch):
 
 def test_predict_variance_paths_agree(monkeypatch):
     """Chunked launches (several rounds of tiles), the legacy kernel (ALABI_PV_LEGACY=1, also used for d > 16) and the
-    default path give the same variances to rounding; d = 20 exercises the legacy dispatch on its own."""
+    default path give the same variances to rounding; d = 20 (cached-inverse path with a wide K* pre-pass) and d = 40 (legacy
+    dispatch on its own) against the oracle."""
     from alabi_amd import HipGP
     from oracle.gp_oracle import OracleGP
     X, y, h = make_problem(500, 6, 8, log_wn=-8.0)
@@ -317,14 +318,16 @@ def test_predict_variance_paths_agree(monkeypatch):
     np.testing.assert_array_equal(out["substitution"][1], out["substitution_chunked"][1])
     for k in ("ALABI_PV_CHUNK_TILES", "ALABI_PV_LEGACY", "ALABI_PV_W"):
         monkeypatch.delenv(k, raising=False)
-    X2, y2, h2 = make_problem(300, 20, 9, log_wn=-8.0, ell2=20.0)
-    g2 = HipGP(20, h2["mean"], h2["log_white_noise"], h2["log_amp"], h2["log_M"]); g2.compute(X2)
-    o2 = OracleGP(20, h2["mean"], h2["log_white_noise"], h2["log_amp"], h2["log_M"]).compute(X2)
-    Xs2 = np.random.RandomState(4).uniform(-3, 3, (300, 20))
-    mu2, var2 = g2.predict(y2, Xs2, return_var=True)
-    mu_o, var_o = o2.predict(y2, Xs2, return_var=True)
-    assert np.max(np.abs(mu2 - mu_o) / (np.abs(mu_o) + 1)) <= 1e-9
-    assert np.max(np.abs(var2 - var_o)) <= 1e-7 * np.exp(h2["log_amp"])
+    for dd in (20, 40):
+        X2, y2, h2 = make_problem(300, dd, 9, log_wn=-8.0, ell2=float(dd))
+        g2 = HipGP(dd, h2["mean"], h2["log_white_noise"], h2["log_amp"], h2["log_M"]); g2.compute(X2)
+        o2 = OracleGP(dd, h2["mean"], h2["log_white_noise"], h2["log_amp"], h2["log_M"]).compute(X2)
+        for Mq in (300, 9):
+            Xs2 = np.random.RandomState(4).uniform(-3, 3, (Mq, dd))
+            mu2, var2 = g2.predict(y2, Xs2, return_var=True)
+            mu_o, var_o = o2.predict(y2, Xs2, return_var=True)
+            assert np.max(np.abs(mu2 - mu_o) / (np.abs(mu_o) + 1)) <= 1e-9
+            assert np.max(np.abs(var2 - var_o)) <= 1e-7 * np.exp(h2["log_amp"])
 
 
 @pytest.mark.parametrize("N,d", [(300, 4), (1000, 10), (257, 1)])
