@@ -276,10 +276,12 @@ __shared__ double ws_dis[2][64];
 // (vmcnt(0)), which would drain the stage that is meant to stay in flight.
 template <int TM>
 __device__ __attribute__((noinline)) void
-ws_produce_tile(const double* L_, const double* dinv_, int Npad, const double* V_) {
+ws_produce_tile(const double* L_, const double* dinv_, int Npad, const double* V_, int kb0) {
     const ws_gcptr L = (ws_gcptr)L_, dinv = (ws_gcptr)dinv_, V = (ws_gcptr)V_;
     const int t8 = threadIdx.x - 256;          // 256 producer threads: 8 + 8 loads per stage each
-    const int nb = Npad / 64, ld = Npad, nstages = nb * (nb + 1) / 2;
+    // kb0: first block row with a non-zero right-hand side (0 for predictions; the tile's own block row when the columns of
+    // the identity are pushed through to build L^-1): the stage sequence is (kb, s), kb0 <= s <= kb < nb
+    const int nb = Npad / 64, ld = Npad, nr = nb - kb0, nstages = nr * (nr + 1) / 2;
     // Two register sets; every stage issues exactly 8 + TM/8 + 1 loads (a diagonal stage loads a V block it does not use), so
     // the wait for the OLDER set is a constant vmcnt and the younger set stays in flight.
     f64x2 pa[2][8], pv[2][TM / 8];
@@ -290,7 +292,7 @@ ws_produce_tile(const double* L_, const double* dinv_, int Npad, const double* V
 #define ALABI_WS_ISSUE(SET, KB, S)                                                                            \
     {                                                                                                         \
         const ws_gcptr2 Lb_ = (ws_gcptr2)(L + ((size_t)((KB) * 64 + prow)) * ld + (S) * 64) + pch;            \
-        const ws_gcptr2 Vj_ = (ws_gcptr2)(V + ((size_t)(((S) < (KB) ? (S) : 0) * 64 + prow)) * TM) + pch;     \
+        const ws_gcptr2 Vj_ = (ws_gcptr2)(V + ((size_t)(((S) < (KB) ? (S) : kb0) * 64 + prow)) * TM) + pch;   \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) pa[SET][i] = Lb_[4 * i];                                \
         _Pragma("unroll") for (int i = 0; i < TM / 8; ++i) pv[SET][i] = Vj_[4 * i];                           \
         pd[SET] = dinv[(KB) * 64 + (t8 & 63)];                                                                \
@@ -303,31 +305,31 @@ ws_produce_tile(const double* L_, const double* dinv_, int Npad, const double* V
         if (WITH_V) { _Pragma("unroll") for (int i = 0; i < TM / 8; ++i) vs_[4 * i] = pv[SET][i]; }           \
         if (t8 < 64) ws_dis[BUF][t8] = pd[SET];                                                               \
     }
-#define ALABI_WS_ADVANCE(KB, S) { if (++(S) > (KB)) { ++(KB); (S) = 0; } }
-    // ---- phase A: block rows 0..3, one stage at a time (a V block may be needed a stage or two after it is produced) ----
-    int b = 0, kb = 0, sj = 0;                 // the stage the consumers are working on
-    ALABI_WS_ISSUE(0, 0, 0)
+#define ALABI_WS_ADVANCE(KB, S) { if (++(S) > (KB)) { ++(KB); (S) = kb0; } }
+    // ---- phase A: block rows kb0..kb0+3, one stage at a time (a V block may be needed a stage or two after it is produced) ----
+    int b = 0, kb = kb0, sj = kb0;             // the stage the consumers are working on
+    ALABI_WS_ISSUE(0, kb0, kb0)
     ALABI_WS_TO_LDS(0, 0, false)
     __syncthreads();                           // stage 0 is in LDS
-    int k1 = 0, s1 = 0;                        // stage b + 1
+    int k1 = kb0, s1 = kb0;                    // stage b + 1
     ALABI_WS_ADVANCE(k1, s1)
-    while (b < nstages && kb < 4) {
+    while (b < nstages && kb < kb0 + 4) {
         const int nbuf = (b & 1) ^ 1;
         const bool diag = sj == kb;
         if (b > 0) __syncthreads();            // stage b is in LDS buffer b & 1; buffer nbuf is free
         if (diag) __syncthreads();             // the consumers' mid-stage barrier
         if (b + 1 < nstages) {
             ALABI_WS_ISSUE(0, k1, s1)
-            // stage (1, 0) needs V_0 the moment it is produced: the consumers hand it over in LDS themselves
+            // stage (kb0 + 1, kb0) needs V_kb0 the moment it is produced: the consumers hand it over in LDS themselves
             ALABI_WS_TO_LDS(0, nbuf, (s1 < k1 && b > 0))
         }
         ++b;
         ALABI_WS_ADVANCE(kb, sj)
         ALABI_WS_ADVANCE(k1, s1)
     }
-    // ---- phase B: block rows >= 4, two stages ahead.  Set 1 holds stage b + 1 for even b - bA, set 0 for odd. ----
+    // ---- phase B: block rows >= kb0 + 4, two stages ahead.  Set 1 holds stage b + 1 for even b - bA, set 0 for odd. ----
     if (b < nstages) {
-        // here (kb, sj) = (4, 0) = stage b (already in LDS), (k1, s1) = stage b + 1
+        // here (kb, sj) = (kb0 + 4, kb0) = stage b (already in LDS), (k1, s1) = stage b + 1
         int k2 = k1, s2 = s1;
         ALABI_WS_ADVANCE(k2, s2)               // stage b + 2
         ALABI_WS_ISSUE(1, k1, s1)
@@ -360,7 +362,7 @@ ws_produce_tile(const double* L_, const double* dinv_, int Npad, const double* V
 // Consumer waves of one tile: returns this lane's share of |L^-1 k*|^2 (before the cross-lane fold).
 template <int TM>
 __device__ __attribute__((noinline)) double
-ws_consume_tile(int Npad, double* V_) {
+ws_consume_tile(int Npad, double* V_, int kb0) {
     constexpr int NT = TM / 16;            // MFMA column tiles per wave
     constexpr int CPW = TM / 4;            // solve: columns per wave ...
     constexpr int LPC = 64 / CPW;          // ... lanes per column (lane group g holds rows g, g + LPC, ...)
@@ -377,10 +379,10 @@ ws_consume_tile(int Npad, double* V_) {
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[n][i] = V[(size_t)(16 * w + lk + 4 * i) * TM + 16 * n + lr];
+        for (int i = 0; i < 4; ++i) acc[n][i] = V[(size_t)(kb0 * 64 + 16 * w + lk + 4 * i) * TM + 16 * n + lr];
     int b = 0;
-    for (int kb = 0; kb < nb; ++kb)
-        for (int sj = 0; sj <= kb; ++sj, ++b) {
+    for (int kb = kb0; kb < nb; ++kb)
+        for (int sj = kb0; sj <= kb; ++sj, ++b) {
             const int buf = b & 1, nbuf = buf ^ 1;
             if (b > 0) __syncthreads();    // stage b is in LDS buffer buf
             if (sj < kb) {
@@ -428,7 +430,7 @@ ws_consume_tile(int Npad, double* V_) {
 #pragma unroll
             for (int t = 0; t < RPL; ++t) {
                 V[(size_t)(kb * 64 + LPC * t + g) * TM + col] = v[t];
-                if (kb == 0) ws_Vs[nbuf][LPC * t + g][col] = v[t];   // stage (1, 0) follows at once: hand V_0 over in LDS
+                if (kb == kb0) ws_Vs[nbuf][LPC * t + g][col] = v[t];   // the next stage needs this block at once: LDS hand-over
                 ss = fma(v[t], v[t], ss);
             }
         }
@@ -487,7 +489,7 @@ predict_kstar_tile_kernel(const double* __restrict__ Xt, const double* __restric
 template <int TM>
 __global__ void __launch_bounds__(512)
 predict_var_ws_kernel(const double* __restrict__ L, const double* __restrict__ dinv, int Npad, long long M, double amp,
-                      double* __restrict__ ws, double* __restrict__ var) {
+                      double* __restrict__ ws, double* __restrict__ var, int ident) {
     constexpr int CPW = TM / 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -495,10 +497,12 @@ predict_var_ws_kernel(const double* __restrict__ L, const double* __restrict__ d
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         double* V = ws + (size_t)tile * Npad * TM;
         __syncthreads();                       // the previous tile is completely finished with the LDS stages
+        // identity right-hand sides (building L^-1): query m is column m, zero above its own block row
+        const int kb0 = ident ? (int)((tile * TM) / 64) : 0;
         if (wv >= 4) {
-            ws_produce_tile<TM>(L, dinv, Npad, V);
+            ws_produce_tile<TM>(L, dinv, Npad, V, kb0);
         } else {
-            double ss = ws_consume_tile<TM>(Npad, V);   // lane (column lane % CPW, row group lane / CPW) of wave wv's columns
+            double ss = ws_consume_tile<TM>(Npad, V, kb0);   // lane (column lane % CPW, row group lane / CPW) of wave wv's columns
 #pragma unroll
             for (int off = CPW; off < 64; off <<= 1) ss += __shfl_xor(ss, off, 64);
             const long long mc = tile * TM + CPW * wv + (lane % CPW);
@@ -776,10 +780,10 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
             const int grid_c = (int)(tiles_c < n_cu ? tiles_c : n_cu);
             if (TM == 16)
                 hipLaunchKernelGGL(predict_var_ws_kernel<16>, dim3(grid_c), dim3(512), 0, s, gp->L, gp->dinv, gp->Npad, mc, amp,
-                                   gp->ws, var + m0);
+                                   gp->ws, var + m0, 0);
             else
                 hipLaunchKernelGGL(predict_var_ws_kernel<64>, dim3(grid_c), dim3(512), 0, s, gp->L, gp->dinv, gp->Npad, mc, amp,
-                                   gp->ws, var + m0);
+                                   gp->ws, var + m0, 0);
         }
         ALABI_LAUNCH_CHECK();
         return ALABI_OK;
@@ -851,7 +855,7 @@ int launch_factor_inverse_into(alabi_gp* gp, double* dst, hipStream_t s) {
         const int tiles = gp->Npad / 16;
         hipLaunchKernelGGL(ident_seed_kernel, dim3(1024), dim3(256), 0, s, gp->ws, gp->Npad);
         hipLaunchKernelGGL(predict_var_ws_kernel<16>, dim3(tiles < n_cu ? tiles : n_cu), dim3(512), 0, s, gp->L, gp->dinv, gp->Npad,
-                           (long long)gp->Npad, 0.0, gp->ws, gp->work);
+                           (long long)gp->Npad, 0.0, gp->ws, gp->work, 1);
         hipLaunchKernelGGL(retile_16_to_64_kernel, dim3(1024), dim3(256), 0, s, gp->ws, dst, gp->Npad);
         ALABI_LAUNCH_CHECK();
         return ALABI_OK;
