@@ -42,6 +42,8 @@ SIGNATURES = {
     "alabi_gp_logdet": (_i, [_vp, _pd, _vp]),
     "alabi_gp_nll": (_i, [_vp, _pd, _vp]),
     "alabi_gp_grad_log_likelihood": (_i, [_vp, _pd, _vp]),
+    "alabi_gp_append": (_i, [_vp, _vp, _vp]),
+    "alabi_gp_set_mean": (_i, [_vp, _d]),
     "alabi_gp_get_alpha": (_i, [_vp, _vp, _vp]),
     "alabi_gp_get_factor": (_i, [_vp, _vp, _vp]),
     "alabi_gp_n": (_i, [_vp, _pi]),

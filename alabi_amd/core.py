@@ -407,7 +407,8 @@ class SurrogateModel(object):
                 raise ValueError("Reoptimized GP still has invalid parameters")
             return gp, time.time() - t0
         gp = self.set_hyperparameter_vector(gp, hyperparameters)
-        gp.compute(_theta)
+        # one more training point, same kernel hyper-parameters: extend the previous factor instead of refactorising
+        gp.compute_from(getattr(self, "gp", None), _theta)
         return gp, time.time() - t0
 
     def _opt_gp(self, hyperopt_method="ml", regularize=True, amp_0=1.0, mu_0=1.0, sigma_0=2.0,

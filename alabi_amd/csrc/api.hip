@@ -187,6 +187,33 @@ int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream) {
     return ALABI_OK;
 }
 
+int alabi_gp_append(alabi_gp* gp, const double* x_new, void* stream) {
+    if (!gp || !x_new) return ALABI_BAD_ARGUMENT;
+    if (!gp->computed) return ALABI_NOT_COMPUTED;
+    if (gp->N >= gp->Npad || gp->N + 1 > gp->n_cap) return ALABI_BAD_ARGUMENT;      // no padding row left: refit
+    hipStream_t s = as_stream(stream);
+    int st = ensure_winv(gp, s);
+    if (st == ALABI_NOT_COMPUTED) return ALABI_BAD_ARGUMENT;                          // no room for the cached L^-1: refit
+    if (st != ALABI_OK) return st;
+    if ((st = launch_append(gp, x_new, s)) != ALABI_OK) return st;
+    int info = 0;
+    ALABI_HIP_CHECK(hipMemcpyAsync(&info, gp->info, sizeof(int), hipMemcpyDeviceToHost, s));
+    ALABI_HIP_CHECK(hipStreamSynchronize(s));
+    gp->last_pivot = info;
+    if (info != 0) return ALABI_NOT_POSITIVE_DEFINITE;                                // factor and cache untouched
+    gp->N += 1;
+    gp->has_alpha = false;
+    gp->gen++; gp->factor_gen++;
+    gp->winv_gen = gp->factor_gen;                                                    // the cache was extended with the factor
+    return ALABI_OK;
+}
+
+int alabi_gp_set_mean(alabi_gp* gp, double mean) {
+    if (!gp || !std::isfinite(mean)) return ALABI_BAD_ARGUMENT;
+    if (mean != gp->mean) { gp->mean = mean; gp->has_alpha = false; gp->gen++; }
+    return ALABI_OK;
+}
+
 int alabi_gp_last_pivot(alabi_gp* gp, int* pivot) {
     if (!gp || !pivot) return ALABI_BAD_ARGUMENT;
     *pivot = gp->last_pivot;

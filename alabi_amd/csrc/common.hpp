@@ -156,6 +156,7 @@ void* dev_cache_take(size_t need, size_t* bytes);   // a cached buffer of at lea
 void dev_cache_give(void* p, size_t bytes);         // hand a buffer back (may free it or another one)
 int dev_alloc_cached(void** p, size_t need, size_t* bytes);   // cache first, then hipMalloc; hipError_t as int
 int launch_factor_inverse(alabi_gp* gp, hipStream_t s);
+int launch_append(alabi_gp* gp, const double* x_new, hipStream_t s);   // gp_append.hip
 int want_winv(alabi_gp* gp, long long M);            // counts the request; 1 when the cached L^-1 should serve it
 int ensure_winv(alabi_gp* gp, hipStream_t s);        // the cached L^-1 of the current factor in gp->winv (ALABI_NOT_COMPUTED: no room)
 int launch_factor_inverse_into(alabi_gp* gp, double* dst, hipStream_t s);

@@ -14,6 +14,7 @@ moves arrays and keeps the hyper-parameter vector.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -264,6 +265,41 @@ class HipGP:
         self.computed = True
         self.dirty = False
         return True
+
+    def compute_from(self, prev, x, quiet=False):
+        """``compute(x)``; when ``prev`` (another HipGP) holds the factorisation of ``x[:-1]`` with the same kernel
+        hyper-parameters, its device handle is taken over and the last row is APPENDED in O(N^2) (alabi_gp_append) instead of
+        refactorising -- the reference's refit after every active-learning iteration (core.py:1780 -> :1158).  ``prev`` is
+        left uncomputed (it refactorises on demand if it is used again)."""
+        try:
+            xa = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+            ok = (os.environ.get("ALABI_NO_APPEND", "0") != "1"
+                  and prev is not None and prev is not self and isinstance(prev, HipGP) and prev.computed and not prev.dirty
+                  and prev._handle is not None and self._handle is None and prev.ndim == self.ndim
+                  and prev.kernel_name == self.kernel_name and prev.log_alpha == self.log_alpha
+                  and prev.white_noise_value == self.white_noise_value and prev.log_constant == self.log_constant
+                  and np.array_equal(prev.log_M, self.log_M) and xa.ndim == 2 and xa.shape[0] == prev._n + 1
+                  and prev._n % 64 != 0 and prev._n + 1 <= prev._cap and isinstance(prev._x, np.ndarray)
+                  and prev._x.shape == (prev._n, self.ndim) and np.array_equal(prev._x, xa[:-1]))
+        except Exception:  # noqa: BLE001
+            ok = False
+        if ok:
+            handle, cap, n_prev = prev._handle, prev._cap, prev._n
+            x_last = torch.as_tensor(xa[-1], device=_dev())
+            st = _lib.lib().alabi_gp_set_mean(handle, self.mean_value)
+            if st == _lib.OK:
+                st = _lib.lib().alabi_gp_append(handle, _lib.ptr(x_last), _lib.current_stream())
+            if st == _lib.OK:
+                prev._handle, prev._cap = None, 0
+                prev.computed, prev.dirty, prev._y_set, prev._x_dev = False, True, False, None
+                self._handle, self._cap = handle, cap
+                self._x, self._x_dev, self._n = xa, None, n_prev + 1
+                self._restore = False
+                self._y_set, self._alpha_host = False, None
+                self.computed, self.dirty = True, False
+                self.appended = getattr(prev, "appended", 0) + 1
+                return True
+        return self.compute(x, quiet=quiet)
 
     def recompute(self, quiet=False, **kw):
         if self._x is None:

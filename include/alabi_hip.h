@@ -66,6 +66,16 @@ int alabi_gp_set_kernel(alabi_gp* gp, int kernel_type, double log_alpha);
 int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream);
 int alabi_gp_last_pivot(alabi_gp* gp, int* pivot /* host, 1-based like LAPACK info */);
 
+/* Extend the factorisation by ONE training point x_new[d] (device) with the hyper-parameters unchanged: the refit after every
+ * active-learning iteration (alabi/core.py:1780 -> _fit_gp -> gp.compute at :1158) in O(N^2) through the cached L^-1 instead
+ * of O(N^3).  Needs a free padding row (N not a multiple of 64 and N < n_cap): ALABI_BAD_ARGUMENT otherwise -- call
+ * alabi_gp_compute then.  ALABI_NOT_POSITIVE_DEFINITE leaves the factor as it was.  Invalidates alpha (call alabi_gp_set_y).
+ * SYNCHRONISES the stream. */
+int alabi_gp_append(alabi_gp* gp, const double* x_new, void* stream);
+
+/* Change the constant mean only (it does not enter K): keeps the factorisation, invalidates alpha. */
+int alabi_gp_set_mean(alabi_gp* gp, double mean);
+
 /* alpha = K^-1 (y - mean): george _compute_alpha inside gp.predict -- alabi/core.py:85. */
 int alabi_gp_set_y(alabi_gp* gp, const double* y, void* stream);
 

@@ -359,3 +359,49 @@ def test_small_batch_variance_path(N, d, monkeypatch):
     mu, var = g.predict(y[: N - 70], Xs, return_var=True)
     mu_o, var_o = o.predict(y[: N - 70], Xs, return_var=True)
     assert np.max(np.abs(var - var_o)) <= 1e-7 * amp and np.max(np.abs(mu - mu_o) / (np.abs(mu_o) + 1)) <= 1e-9
+
+
+def test_append_point_matches_full_factorisation():
+    """HipGP.compute_from takes over the previous factor and appends one row (alabi_gp_append): factor, log-determinant,
+    predictions (all three variance paths), likelihood and gradient must match a full factorisation / the oracle; the append
+    is refused (full refit) when the padding rows are used up, and a point that breaks positive definiteness leaves the old
+    factor usable."""
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    d = 3
+    X, y, h = make_problem(200, d, 55, log_wn=-8.0)
+    amp = np.exp(h["log_amp"])
+    mk = lambda: HipGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"])  # noqa: E731
+    g = mk(); g.compute(X[:120])
+    appended = 0
+    for n in range(121, 200):
+        g2 = mk()
+        g2.compute_from(g, X[:n])
+        if getattr(g2, "appended", 0) > appended:
+            appended = g2.appended
+        g = g2
+        if n in (121, 128, 129, 150, 192, 193, 199):
+            o = OracleGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X[:n])
+            Lf = g.solver.get_factor().cpu().numpy()
+            assert np.max(np.abs(Lf - o._L)) <= 1e-9 * np.max(np.abs(o._L))
+            for M in (7, 300, 5000):
+                Xs = np.random.RandomState(n + M).uniform(-3, 3, (M, d))
+                mu, var = g.predict(y[:n], Xs, return_var=True)
+                mu_o, var_o = o.predict(y[:n], Xs, return_var=True)
+                assert np.max(np.abs(mu - mu_o) / (np.abs(mu_o) + 1)) <= 1e-8
+                assert np.max(np.abs(var - var_o)) <= 1e-7 * amp
+            assert abs(g.log_likelihood(y[:n]) - o.log_likelihood(y[:n])) <= 1e-8 * abs(o.log_likelihood(y[:n]))
+            np.testing.assert_allclose(g.grad_log_likelihood(y[:n]), o.grad_log_likelihood(y[:n]), rtol=1e-6,
+                                       atol=1e-7 * np.max(np.abs(o.grad_log_likelihood(y[:n]))))
+    # 79 steps, refits at the two 64-row boundaries (128 -> 129, 192 -> 193) only... counted through the chain of objects
+    assert appended >= 60
+    # a duplicate of an existing point with a negligible nugget: whatever the extended factor does (refused append + failed or
+    # barely passing refit), the previous object must stay usable (it kept its factor or rebuilds it)
+    gd = HipGP(d, h["mean"], -40.0, h["log_amp"], h["log_M"]); gd.compute(X[:100])
+    gbad = HipGP(d, h["mean"], -40.0, h["log_amp"], h["log_M"])
+    try:
+        gbad.compute_from(gd, np.vstack([X[:100], X[:1]]))
+    except np.linalg.LinAlgError:
+        pass
+    mu = gd.predict(y[:100], X[:5], return_cov=False)
+    assert np.all(np.isfinite(mu))

@@ -157,3 +157,32 @@ def test_run_emcee_with_normal_prior(tmp_path):
         assert abs(sm.emcee_samples[:, 0].mean() - data[0][0]) < 3 * data[0][1]
     with pytest.raises(NotImplementedError):
         sm.run_emcee(prior_fn=lambda t: 0.0, nwalkers=20, nsteps=10)
+
+
+def test_active_train_uses_append_and_matches_full_refits(tmp_path, monkeypatch):
+    """active_train extends the factor by one row per iteration; the GP it ends with predicts exactly like a GP factorised
+    from scratch on the same training set with the same hyper-parameters (the acquisition arg-min is chaotic in the last
+    bits, so trajectories of two runs are not compared point by point)."""
+    from alabi_amd import HipGP, SurrogateModel
+    from alabi_amd.benchmarks import gaussian_2d
+    for tag, env in (("append", "0"), ("full", "1")):
+        monkeypatch.setenv("ALABI_NO_APPEND", env)
+        sm = SurrogateModel(lnlike_fn=gaussian_2d["fn"], bounds=gaussian_2d["bounds"], savedir=str(tmp_path), verbose=False,
+                            random_state=1, cache=False)
+        sm.init_samples(ntrain=70)
+        sm.init_gp(hyperopt_method="ml", gp_nopt=1, optimizer_kwargs={"maxiter": 10})
+        sm.active_train(niter=12, algorithm="bape", gp_opt_freq=1000, optimizer_kwargs={"ncand": 4096})
+        n_app = getattr(sm.gp, "appended", 0)
+        assert (n_app >= 8) if tag == "append" else (n_app == 0)
+        assert sm._theta.shape[0] == 82
+        fresh = HipGP(2, kernel=sm.gp.kernel_name, fit_mean=sm.gp.fit_mean, fit_white_noise=sm.gp.fit_white_noise)
+        fresh.mean_value, fresh.white_noise_value = sm.gp.mean_value, sm.gp.white_noise_value
+        fresh.log_constant, fresh.log_M = sm.gp.log_constant, sm.gp.log_M.copy()
+        monkeypatch.setenv("ALABI_NO_APPEND", "1")
+        fresh.compute(sm._theta)
+        Xs = np.random.RandomState(0).uniform(0.05, 0.95, (400, 2)) * (sm._bounds[:, 1] - sm._bounds[:, 0]) + sm._bounds[:, 0]
+        mu_a, var_a = sm.gp.predict(sm._y, Xs, return_var=True)
+        mu_f, var_f = fresh.predict(sm._y, Xs, return_var=True)
+        amp = np.exp(sm.gp.log_constant)
+        assert np.max(np.abs(mu_a - mu_f)) <= 1e-8 * (np.max(np.abs(mu_f)) + 1)
+        assert np.max(np.abs(var_a - var_f)) <= 1e-8 * max(amp, np.max(np.abs(var_f)))
