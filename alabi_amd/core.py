@@ -661,8 +661,11 @@ class SurrogateModel(object):
                 obj_fn = partial(self.utility, predict_gp=predict_gp, bounds=self._bounds)
             for k in ("ncand", "polish", "refine", "nrefine", "ntop"):
                 kw.pop(k, None)
+            grad_obj_fn = None           # analytic gradient on the GPU (reference: core.py:1618-1625 passes grad_utility)
+            if getattr(self, "use_grad_opt", True) and getattr(self, "grad_utility", None) is not None:
+                grad_obj_fn = partial(self.grad_utility, gp=self.gp, bounds=self._bounds)
             _thetaN, _ = ut.minimize_objective(obj_fn, bounds=self._bounds, nopt=nopt, ps=self._prior_sampler,
-                                               method=self.obj_opt_method, options=kw or None, grad_obj_fn=None)
+                                               method=self.obj_opt_method, options=kw or None, grad_obj_fn=grad_obj_fn)
         opt_timing = time.time() - t0
         if not np.all(np.isfinite(_thetaN)):
             print("Warning: Acquisition function optimization failed. Falling back to random sampling.")
@@ -685,10 +688,13 @@ class SurrogateModel(object):
         """Active-learning loop: pick a point, evaluate the true function, refit (core.py:1670-1865)."""
         self.algorithm = str(algorithm).lower()
         self.utility, self.grad_utility = ut.assign_utility(self.algorithm)
+        if not use_grad_opt:
+            self.grad_utility = None
         if self.algorithm not in ("bape", "agp", "jones"):
             self.algorithm = "bape"
         self.gp_opt_freq = gp_opt_freq
         self.obj_opt_method = obj_opt_method
+        self.use_grad_opt = bool(use_grad_opt)
         res = self.training_results
         first_iter = res["iteration"][-1] if len(res["iteration"]) else 0
         if self.verbose:

@@ -145,6 +145,7 @@ int alabi_gp_destroy(alabi_gp* gp) {
     if (gp->scan) (void)hipFree(gp->scan);
     alabi::dev_cache_give(gp->winv, gp->winv_bytes);
     if (gp->small) (void)hipFree(gp->small);
+    if (gp->pgrad) (void)hipFree(gp->pgrad);
     delete gp;
     return ALABI_OK;
 }
@@ -256,6 +257,14 @@ int alabi_gp_predict(alabi_gp* gp, const double* Xs, long long M, double* mu, do
         return launch_predict_var(gp, Xs, M, mu, var, s);
     }
     return launch_predict_mean(gp, Xs, M, mu, s);
+}
+
+int alabi_gp_predict_grad(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var, double* dmu, double* dvar,
+                          void* stream) {
+    if (!gp || M < 0 || (M > 0 && (!Xs || !dmu || !dvar))) return ALABI_BAD_ARGUMENT;
+    if (!gp->computed || !gp->has_alpha) return ALABI_NOT_COMPUTED;
+    if (M == 0) return ALABI_OK;
+    return launch_predict_grad(gp, Xs, M, mu, var, dmu, dvar, as_stream(stream));
 }
 
 static int gp_reductions_to_host(alabi_gp* gp, double out[2], hipStream_t s) {

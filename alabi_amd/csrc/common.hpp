@@ -85,6 +85,8 @@ struct alabi_gp {
     int var_requests = 0;     // variance requests seen for the current factor (decides when the cache pays)
     double* small = nullptr;  // [Npad / 64][16] partial sums of the small-batch variance kernel
     size_t small_bytes = 0;
+    double* pgrad = nullptr;  // scratch of the query-gradient path (v, |v|^2 partials, z parts)
+    size_t pgrad_bytes = 0;
 };
 
 namespace alabi {
@@ -157,6 +159,8 @@ void dev_cache_give(void* p, size_t bytes);         // hand a buffer back (may f
 int dev_alloc_cached(void** p, size_t need, size_t* bytes);   // cache first, then hipMalloc; hipError_t as int
 int launch_factor_inverse(alabi_gp* gp, hipStream_t s);
 int launch_append(alabi_gp* gp, const double* x_new, hipStream_t s);   // gp_append.hip
+int launch_predict_grad(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var, double* dmu, double* dvar,
+                        hipStream_t s);                                  // gp_predict_grad.hip
 int want_winv(alabi_gp* gp, long long M);            // counts the request; 1 when the cached L^-1 should serve it
 int ensure_winv(alabi_gp* gp, hipStream_t s);        // the cached L^-1 of the current factor in gp->winv (ALABI_NOT_COMPUTED: no room)
 int launch_factor_inverse_into(alabi_gp* gp, double* dst, hipStream_t s);

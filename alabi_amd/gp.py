@@ -351,6 +351,26 @@ class HipGP:
         _lib.check(st, "alabi_gp_predict")
         return (mu, var) if return_var else mu
 
+    def predict_grad_device(self, y, t):
+        """(mu[M], var[M], dmu[M,d], dvar[M,d]) at the query points t, gradients with respect to t.
+
+        Closed-form replacement of grad_gp_mean_prediction / grad_gp_var_prediction (utility.py:558-623):
+        dmu = (dk/dx)^T alpha, dvar = -2 (dk/dx)^T K^-1 k, device tensors in and out."""
+        self._require_computed()
+        self._set_y(y)
+        td = _to_dev(t, 2)
+        if td.shape[1] != self.ndim:
+            raise ValueError(f"t has {td.shape[1]} columns, GP has ndim={self.ndim}")
+        m = int(td.shape[0])
+        mu = torch.empty(m, dtype=torch.float64, device=td.device)
+        var = torch.empty(m, dtype=torch.float64, device=td.device)
+        dmu = torch.empty((m, self.ndim), dtype=torch.float64, device=td.device)
+        dvar = torch.empty((m, self.ndim), dtype=torch.float64, device=td.device)
+        st = _lib.lib().alabi_gp_predict_grad(self._handle, _lib.ptr(td), m, _lib.ptr(mu), _lib.ptr(var), _lib.ptr(dmu),
+                                              _lib.ptr(dvar), _lib.current_stream())
+        _lib.check(st, "alabi_gp_predict_grad")
+        return mu, var, dmu, dvar
+
     def predict(self, y, t, return_cov=True, return_var=False, cache=True, kernel=None):
         """george GP.predict (core.py:85, :95, :1441, :1601).  return_var wins over return_cov."""
         if return_var:

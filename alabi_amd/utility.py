@@ -26,7 +26,8 @@ from . import _lib
 __all__ = ["agp_utility", "bape_utility", "jones_utility", "assign_utility", "minimize_objective",
            "prior_sampler", "lnprior_uniform", "lnprior_normal", "prior_transform_uniform", "logsubexp",
            "NewFunctionTransformer", "nlog_scaler", "log_scaler", "no_scaler",
-           "utility_scan", "utility_eval_device"]
+           "utility_scan", "utility_eval_device", "grad_gp_mean_prediction", "grad_gp_var_prediction",
+           "grad_agp_utility", "grad_bape_utility"]
 
 
 class NewFunctionTransformer(FunctionTransformer):
@@ -167,14 +168,53 @@ def jones_utility(theta, predict_gp, bounds, y_best, zeta=0.01):
     return float(-((mu - y_best - zeta) * norm.cdf(z) + std * norm.pdf(z)))
 
 
+def _predict_grad(xs, gp):
+    xs = np.asarray(xs, dtype=np.float64).reshape(1, -1)
+    mu, var, dmu, dvar = gp.predict_grad_device(gp._y, xs)
+    return float(mu[0]), float(var[0]), dmu[0].cpu().numpy(), dvar[0].cpu().numpy()
+
+
+def grad_gp_mean_prediction(xs, gp):
+    """grad mu(x) = (dk/dx)^T alpha (utility.py:558-583), closed-form kernel derivative on the GPU
+    (the reference differences the kernel numerically with step 1e-6, utility.py:511-555)."""
+    return _predict_grad(xs, gp)[2]
+
+
+def grad_gp_var_prediction(xs, gp):
+    """grad var(x) = -2 (dk/dx)^T K^-1 k (utility.py:586-623) from the cached L^-1, no explicit K^-1."""
+    return _predict_grad(xs, gp)[3]
+
+
+def grad_agp_utility(theta, gp, bounds):
+    """-(d_mu + 0.5 d_var), the reference's expression (utility.py:704-726: d_var is NOT divided by var there);
+    inf[d] outside the box."""
+    theta = np.asarray(theta, dtype=np.float64).flatten()
+    if not np.isfinite(lnprior_uniform(theta, bounds)):
+        return np.full(len(theta), np.inf)
+    _, _, d_mu, d_var = _predict_grad(theta, gp)
+    return (-(d_mu + 0.5 * d_var)).flatten()
+
+
+def grad_bape_utility(theta, gp, bounds):
+    """-2 d_mu - (1 + e^var / (e^var - 1)) d_var (utility.py:813-850); inf[d] outside the box.
+    e^var / (e^var - 1) is evaluated as 1 / (1 - e^-var): the same number, but finite for var > 709 where the
+    reference's literal expression is inf / inf = NaN."""
+    theta = np.asarray(theta, dtype=np.float64).flatten()
+    if not np.isfinite(lnprior_uniform(theta, bounds)):
+        return np.full(len(theta), np.inf)
+    _, var, d_mu, d_var = _predict_grad(theta, gp)
+    with np.errstate(all="ignore"):
+        return -2.0 * d_mu - (1.0 - 1.0 / np.expm1(-var)) * d_var
+
+
 def assign_utility(algorithm):
-    """name -> (utility, grad_utility)  (utility.py:949-966).  Analytic gradients are not provided
-    (SURVEY.md section 8(f) #4): optimisers fall back to scipy's finite differences."""
-    table = {"bape": bape_utility, "agp": agp_utility, "jones": jones_utility}
+    """name -> (utility, grad_utility)  (utility.py:949-966); jones has no gradient in the reference either."""
+    table = {"bape": (bape_utility, grad_bape_utility), "agp": (agp_utility, grad_agp_utility),
+             "jones": (jones_utility, None)}
     if algorithm not in table:
         print(f"ERROR: Unknown utility function: {algorithm}. Defaulting to BAPE.")
-        return bape_utility, None
-    return table[algorithm], None
+        return table["bape"]
+    return table[algorithm]
 
 
 # ---- device batch forms ---------------------------------------------------------------------

@@ -88,6 +88,15 @@ int alabi_gp_set_y(alabi_gp* gp, const double* y, void* stream);
 int alabi_gp_predict(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var,
                      void* stream);
 
+/* Prediction with gradients with respect to the query point, for the acquisition optimiser:
+ * grad_gp_mean_prediction / grad_gp_var_prediction -- alabi/utility.py:558-623, which difference the kernel numerically
+ * (utility.py:511-555, step 1e-6) and form K^-1 explicitly (solver.get_inverse(), utility.py:610).  Here
+ * dmu[M,d] = (dk / dx)^T alpha and dvar[M,d] = -2 (dk / dx)^T K^-1 k with the closed-form kernel derivative and
+ * K^-1 k = W^T (W k), W = cached L^-1; queries are processed 16 at a time.  mu[M] / var[M] may be NULL.
+ * All pointers are device pointers.  ALABI_HIP_ERROR when there is no room for the L^-1 cache. */
+int alabi_gp_predict_grad(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var,
+                          double* dmu, double* dvar, void* stream);
+
 /* solver.log_determinant and -gp.log_likelihood(y) -- alabi/core.py:1248; gp_utils.py:139.
  * Both SYNCHRONISE the stream and write one host double. */
 int alabi_gp_logdet(alabi_gp* gp, double* out, void* stream);

@@ -19,6 +19,12 @@ def golden():
     return dict(np.load(path))
 
 
+@pytest.fixture(scope="session")
+def golden_grad():
+    """Acquisition-gradient vectors from the reference's utility.py (tests/golden/make_golden_grad.py)."""
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "reference_grad_vectors.npz")))
+
+
 def make_problem(N, d, seed, log_wn=-12.0, ell2=None):
     """Synthetic training set on a smooth target (SURVEY.md section 8(d) recipe, scaled down)."""
     rng = np.random.RandomState(seed)

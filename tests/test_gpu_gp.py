@@ -405,3 +405,62 @@ def test_append_point_matches_full_factorisation():
         pass
     mu = gd.predict(y[:100], X[:5], return_cov=False)
     assert np.all(np.isfinite(mu))
+
+
+@pytest.mark.parametrize("N,d,M,kernel", [(40, 3, 24, "ExpSquaredKernel"), (500, 5, 7, "ExpSquaredKernel"),
+                                          (2000, 10, 33, "ExpSquaredKernel"), (300, 4, 16, "Matern52Kernel"),
+                                          (300, 4, 5, "RationalQuadraticKernel"), (130, 20, 3, "ExpSquaredKernel")])
+def test_predict_grad_against_oracle(torch_gpu, N, d, M, kernel):
+    """alabi_gp_predict_grad (closed-form d mu/dx, d var/dx through the cached L^-1) against the oracle: the closed form
+    for the squared exponential (1e-9 of the gradient scale) and the reference-shaped finite differences
+    (utility.py:511-623, step 1e-6) for every kernel family (1e-5)."""
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    from oracle import utility_oracle as uo
+    X, y, h = make_problem(N, d, 11 + d)
+    g = HipGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"], kernel=kernel)
+    g.compute(X)
+    o = OracleGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"], kernel=kernel).compute(X)
+    Xs = np.random.RandomState(5).uniform(-2.5, 2.5, (M, d))
+    mu, var, dmu, dvar = [t.cpu().numpy() for t in g.predict_grad_device(y, Xs)]
+    mu_o, var_o = o.predict(y, Xs, return_var=True)
+    amp = np.exp(h["log_amp"])
+    assert np.max(np.abs(mu - mu_o) / (np.abs(mu_o) + 1)) <= 1e-8
+    assert np.max(np.abs(var - var_o)) <= 1e-6 * amp
+    mu2, var2 = g.predict(y, Xs, return_var=True)                 # same numbers as the predict entry point
+    assert np.max(np.abs(mu - mu2)) <= 1e-10 * (np.max(np.abs(mu2)) + 1) and np.max(np.abs(var - var2)) <= 1e-10 * amp
+    o._compute_alpha(y)
+    nq = min(M, 6)
+    fd_mu = np.array([uo.grad_gp_mean_prediction(t, o) for t in Xs[:nq]])
+    fd_var = np.array([uo.grad_gp_var_prediction(t, o) for t in Xs[:nq]])
+    assert np.max(np.abs(dmu[:nq] - fd_mu)) <= 1e-5 * np.max(np.abs(fd_mu))
+    assert np.max(np.abs(dvar[:nq] - fd_var)) <= 1e-5 * np.max(np.abs(fd_var)) + 1e-7 * amp
+    if kernel == "ExpSquaredKernel":
+        _, _, dmu_o, dvar_o = uo.analytic_predict_grad(o, y, Xs)
+        assert np.max(np.abs(dmu - dmu_o)) <= 1e-9 * np.max(np.abs(dmu_o))
+        assert np.max(np.abs(dvar - dvar_o)) <= 1e-9 * np.max(np.abs(dvar_o)) + 1e-9 * amp
+
+
+def test_grad_utilities_against_reference_vectors(torch_gpu, golden_grad):
+    """grad_gp_mean_prediction / grad_gp_var_prediction / grad_agp_utility / grad_bape_utility of the product (GPU, closed
+    form) against the arrays the reference's own functions returned (finite differences, step 1e-6)."""
+    from alabi_amd import HipGP
+    from alabi_amd import utility as ut
+    g = golden_grad
+    gp = HipGP(g["grad_X"].shape[1], float(g["grad_mean"]), float(g["grad_log_wn"]), float(g["grad_log_amp"]), g["grad_log_M"])
+    gp.compute(g["grad_X"])
+    gp.predict(g["grad_y"], g["grad_X"][:1], return_cov=False)      # sets gp._y as the reference's callers do
+    th, b = g["grad_theta"], g["grad_bounds"]
+    dmu = np.array([ut.grad_gp_mean_prediction(t, gp) for t in th])
+    dvar = np.array([ut.grad_gp_var_prediction(t, gp) for t in th])
+    assert np.max(np.abs(dmu - g["grad_dmu"])) <= 1e-6 * np.max(np.abs(g["grad_dmu"]))
+    assert np.max(np.abs(dvar - g["grad_dvar"])) <= 1e-6 * np.max(np.abs(g["grad_dvar"]))
+    agp = np.array([ut.grad_agp_utility(t, gp, b) for t in th])
+    bape = np.array([ut.grad_bape_utility(t, gp, b) for t in th])
+    assert np.array_equal(np.isinf(agp), np.isinf(g["grad_agp"])) and np.array_equal(np.isinf(bape), np.isinf(g["grad_bape"]))
+    fin = np.isfinite(g["grad_agp"][:, 0])
+    assert np.max(np.abs(agp[fin] - g["grad_agp"][fin])) <= 1e-6 * np.max(np.abs(g["grad_agp"][fin]))
+    _, var = gp.predict(g["grad_y"], th, return_var=True)
+    ok = fin & (var > 1e-9 * np.exp(float(g["grad_log_amp"])))
+    assert ok.sum() >= 15
+    assert np.max(np.abs(bape[ok] - g["grad_bape"][ok]) / (np.abs(g["grad_bape"][ok]) + 1.0)) <= 1e-5

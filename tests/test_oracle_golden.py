@@ -106,3 +106,41 @@ def test_benchmark_likelihoods(golden):
     # gaussian_nd uses the pinned covariance recipe
     gn = bm.gaussian_nd(10, seed=int(g["bench_cov10_seed"]))
     _eq(gn["cov"], g["bench_cov10"], rtol=1e-12)
+
+
+def _grad_gp(g):
+    from oracle.gp_oracle import OracleGP
+    gp = OracleGP(g["grad_X"].shape[1], float(g["grad_mean"]), float(g["grad_log_wn"]), float(g["grad_log_amp"]), g["grad_log_M"])
+    gp.compute(g["grad_X"])
+    gp._compute_alpha(g["grad_y"])
+    return gp
+
+
+def test_acquisition_gradients_reference_shaped(golden_grad):
+    """The oracle's restatement of utility.py:511-850 (numerical kernel gradient, explicit inverse) against the arrays
+    the reference's functions returned on the same GP."""
+    g = golden_grad
+    gp = _grad_gp(g)
+    th, b = g["grad_theta"], g["grad_bounds"]
+    _eq([uo.grad_gp_mean_prediction(t, gp) for t in th], g["grad_dmu"], rtol=1e-9, atol=1e-9)
+    _eq([uo.grad_gp_var_prediction(t, gp) for t in th], g["grad_dvar"], rtol=1e-9, atol=1e-9)
+    _eq([uo.grad_agp_utility(t, gp, b) for t in th], g["grad_agp"], rtol=1e-9, atol=1e-9)
+    _eq([uo.grad_bape_utility(t, gp, b) for t in th], g["grad_bape"], rtol=1e-9, atol=1e-9)
+    assert np.all(np.isinf(g["grad_bape"][-3:])) and np.all(np.isinf(g["grad_agp"][-3:]))
+
+
+def test_acquisition_gradients_closed_form(golden_grad):
+    """The closed form the HIP path evaluates agrees with the reference's finite-difference result to the accuracy of
+    the differencing (step 1e-6: relative 1e-6 of the gradient scale)."""
+    g = golden_grad
+    gp = _grad_gp(g)
+    mu, var, dmu, dvar = uo.analytic_predict_grad(gp, g["grad_y"], g["grad_theta"])
+    sm = np.max(np.abs(g["grad_dmu"])); sv = np.max(np.abs(g["grad_dvar"]))
+    assert np.max(np.abs(dmu - g["grad_dmu"])) <= 1e-6 * sm
+    assert np.max(np.abs(dvar - g["grad_dvar"])) <= 1e-6 * sv
+    inside = np.isfinite(g["grad_bape"][:, 0])
+    with np.errstate(all="ignore"):
+        e = np.exp(var)
+        bape = -2.0 * dmu - (1.0 + e / (e - 1.0))[:, None] * dvar
+    ok = inside & (var > 1e-9 * np.exp(float(g["grad_log_amp"])))     # at a training point var ~ 0 and the weight blows up
+    assert np.max(np.abs(bape[ok] - g["grad_bape"][ok]) / (np.abs(g["grad_bape"][ok]) + np.max(np.abs(bape[ok])))) <= 1e-5
