@@ -5,19 +5,18 @@
 // alabi/gp_utils.py:243.  Work: N^3/3 flops; the dense trailing update runs on the fp64
 // matrix cores (v_mfma_f64_16x16x4_f64) with both 64x64 panels staged in LDS.
 //
-// Per 64-column block step kb:
-//   1. potrf_diag   : ONE wavefront factorises A[kb,kb] left-looking: lane i keeps row i in
-//                     registers, finished rows are published to LDS and re-read as broadcasts,
-//                     so a column costs j independent FMAs + one sqrt/reciprocal and there is no
-//                     workgroup barrier.  A non-positive pivot is reported as LAPACK's potrf
-//                     `info` (1-based).  1/L_jj is kept (dinv) for every later triangular solve.
-//   2. trsm_panel   : A[i,kb] <- A[i,kb] * L_kk^-T.  One lane owns one row (64 rows per wave):
-//                     the substitution along the row needs no cross-lane traffic, L_kk is read
-//                     from LDS as broadcasts, divisions are multiplications by dinv.
-//   3. syrk_update  : A[i,j] -= A[i,kb] * A[j,kb]^T for kb < j <= i, one 64x64 tile per
-//                     workgroup, 4 waves x (16 rows x 64 cols) x K=64 on MFMA.
+// Per 64-column block step kb (two launches; the first diagonal block has its own one-wave launch):
+//   1. trsm_panel   : A[i,kb] <- A[i,kb] * L_kk^-T.  One lane owns one row: the substitution along the
+//                     row is right-looking in registers (two dependent operations per column), L_kk is
+//                     read from LDS as broadcasts, divisions are multiplications by dinv = 1/L_jj.
+//   2. syrk_update  : A[i,j] -= A[i,kb] * A[j,kb]^T for kb < j <= i, one 64x64 tile per workgroup,
+//                     4 waves x (16 rows x 64 cols) x K=64 on MFMA.  The workgroup of tile (kb+1,kb+1)
+//                     then FACTORISES that tile while it is still in LDS (potrf_tile_lds: one wave,
+//                     16-column slabs in registers, v_readlane broadcasts, rank-16 MFMA updates between
+//                     slabs), so the diagonal factorisation costs no launch of its own.  A non-positive
+//                     pivot is reported as LAPACK's potrf `info` (1-based).
 // The matrix is [Npad, Npad] row-major with identity padding, so every block is full.
-#include "common.hpp"
+#include "gp_device.hpp"
 
 namespace alabi {
 
@@ -26,7 +25,8 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // One fp64 MFMA rank-16 update of a 16x16 tile held in LDS:  C -= P Q^T, with P = rows pr.. and Q = rows qr.. of the
 // same 16-column slab (columns c0..c0+15) of `M`.  One wavefront; lane l: A[m=l&15][k=l>>4], B[k=l>>4][n=l&15],
 // C/D row (l>>4)+4i, column l&15.
-__device__ inline void tile_update_16(double (*C)[65], int cr, int cc, double (*Pm)[65], int pr, double (*Qm)[65], int qr,
+template <int LD>
+__device__ inline void tile_update_16(double (*C)[LD], int cr, int cc, double (*Pm)[LD], int pr, double (*Qm)[LD], int qr,
                                       int c0, int lane) {
     const int lr = lane & 15, lk = lane >> 4;
     v4f64 acc;
@@ -53,16 +53,15 @@ __device__ inline void pivot_factors(double piv, double& ljj, double& rinv) {
     rinv = fma(rinv, fma(-ljj, rinv, 1.0), rinv);
 }
 
-// Diagonal block: ONE wavefront, 16-column slabs.  Inside a slab every lane (= row) runs the left-looking column
-// recurrence (dot products of length <= 15 against LDS broadcasts, one rsqrt chain per column); after a slab the
-// trailing tiles get its rank-16 update on the matrix cores.  No workgroup barrier, 64 pivots in sequence.
-__global__ void __launch_bounds__(64)
-potrf_diag_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info, double* __restrict__ dinv) {
-    __shared__ double Ls[64][65];
-    const int lane = threadIdx.x;
-    double* Ab = A + (size_t)(kb * 64) * ld + kb * 64;
-    for (int r = 0; r < 64; ++r) Ls[r][lane] = Ab[(size_t)r * ld + lane];   // coalesced rows
-    __syncthreads();
+// Diagonal block held in LDS (row stride LD doubles), factorised in place by ONE wavefront in 16-column slabs.  Inside a
+// slab every lane (= row) keeps its 16 entries in registers and the recurrence is right-looking: after pivot j the row's
+// remaining slab columns take their rank-1 update at once, L[c0+k][c0+j] arriving by v_readlane from the lane that owns
+// row c0+k, so the dependent chain per column is readlane -> rsqrt/Newton -> scale -> readlane -> one FMA and the other
+// updates fill its shadow.  After a slab the trailing tiles get its rank-16 update on the matrix cores.  A non-positive
+// pivot is reported as LAPACK's potrf `info` (1-based).  Returns 1/L_ii of row `lane`.  `__syncthreads` here is executed
+// by one wave only when the caller's other waves wait at a later barrier, so plain wave-level ordering is used instead.
+template <int LD>
+__device__ inline double potrf_tile_lds(double (*Ls)[LD], int lane, int kb, int* __restrict__ info) {
     double my_rinv = 1.0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -72,34 +71,44 @@ potrf_diag_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info
         for (int j = 0; j < 16; ++j) a[j] = Ls[lane][c0 + j];      // row `lane`, this slab (rows < c0 carry unused values)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int k = 0; k < j; ++k) {
-                const double ljk = Ls[c0 + j][c0 + k];
-                if (k & 1) s1 = fma(a[k], ljk, s1); else s0 = fma(a[k], ljk, s0);
-            }
-            const double v = a[j] - (s0 + s1);
-            double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), c0 + j),
-                                          __builtin_amdgcn_readlane(__double2loint(v), c0 + j));
+            double piv = lane_bcast(a[j], c0 + j);
             if (!(piv > 0.0)) {  // also true for NaN
                 if (lane == 0) atomicCAS(info, 0, kb * 64 + c0 + j + 1);
                 piv = 1.0;
             }
             double ljj, rinv;
             pivot_factors(piv, ljj, rinv);
-            a[j] = (lane == c0 + j) ? ljj : v * rinv;
+            a[j] = (lane == c0 + j) ? ljj : a[j] * rinv;
             if (lane == c0 + j) my_rinv = rinv;
-            Ls[lane][c0 + j] = a[j];
-            __syncthreads();             // single wave: orders the LDS write before the next column's broadcasts
+#pragma unroll
+            for (int k = j + 1; k < 16; ++k) a[k] = fma(-a[j], lane_bcast(a[j], c0 + k), a[k]);
         }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Ls[lane][c0 + j] = a[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // one wave: LDS writes above are ordered before the reads below
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // rank-16 update of the tiles right of / below the slab (lower triangle of the 16x16 tile grid)
 #pragma unroll
         for (int ti = s + 1; ti < 4; ++ti)
 #pragma unroll
-            for (int tk = s + 1; tk <= ti; ++tk) tile_update_16(Ls, 16 * ti, 16 * tk, Ls, 16 * ti, Ls, 16 * tk, c0, lane);
-        __syncthreads();
+            for (int tk = s + 1; tk <= ti; ++tk) tile_update_16<LD>(Ls, 16 * ti, 16 * tk, Ls, 16 * ti, Ls, 16 * tk, c0, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    dinv[kb * 64 + lane] = my_rinv;
+    return my_rinv;
+}
+
+// First diagonal block (the later ones are factorised inside syrk_update_kernel by the workgroup that finishes them).
+__global__ void __launch_bounds__(64)
+potrf_diag_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info, double* __restrict__ dinv) {
+    __shared__ double Ls[64][65];
+    const int lane = threadIdx.x;
+    double* Ab = A + (size_t)(kb * 64) * ld + kb * 64;
+    for (int r = 0; r < 64; ++r) Ls[r][lane] = Ab[(size_t)r * ld + lane];   // coalesced rows
+    __syncthreads();
+    dinv[kb * 64 + lane] = potrf_tile_lds<65>(Ls, lane, kb, info);
     for (int r = 0; r < 64; ++r)
         if (lane <= r) Ab[(size_t)r * ld + lane] = Ls[r][lane];
 }
@@ -130,15 +139,12 @@ trsm_panel_kernel(double* __restrict__ A, int ld, int kb, const double* __restri
             double b[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) b[j] = bs[row][c0 + j];
+            // right-looking along the row: two dependent operations per column (scale, first update), the rest fills in
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                double s0 = 0.0, s1 = 0.0;
+                b[j] *= di[c0 + j];
 #pragma unroll
-                for (int k = 0; k < j; ++k) {
-                    const double ljk = lkk[c0 + j][c0 + k];
-                    if (k & 1) s1 = fma(b[k], ljk, s1); else s0 = fma(b[k], ljk, s0);
-                }
-                b[j] = (b[j] - (s0 + s1)) * di[c0 + j];
+                for (int k = j + 1; k < 16; ++k) b[k] = fma(-b[j], lkk[c0 + k][c0 + j], b[k]);
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j) bs[row][c0 + j] = b[j];
@@ -146,7 +152,7 @@ trsm_panel_kernel(double* __restrict__ A, int ld, int kb, const double* __restri
         __syncthreads();
         // B[rows of this wave, later slabs] -= X_s * L_kk[later rows, slab]^T
 #pragma unroll
-        for (int t = s + 1; t < 4; ++t) tile_update_16(bs, 16 * w, 16 * t, bs, 16 * w, lkk, 16 * t, c0, lane);
+        for (int t = s + 1; t < 4; ++t) tile_update_16<65>(bs, 16 * w, 16 * t, bs, 16 * w, lkk, 16 * t, c0, lane);
         __syncthreads();
     }
     for (int e = tid; e < 4096; e += 256) {
@@ -155,9 +161,11 @@ trsm_panel_kernel(double* __restrict__ A, int ld, int kb, const double* __restri
     }
 }
 
-// C[bi,bj] -= P[bi] * P[bj]^T with P[b] = A[b-block rows, kb-block cols].
+// C[bi,bj] -= P[bi] * P[bj]^T with P[b] = A[b-block rows, kb-block cols].  Workgroup 0 owns the tile (kb+1, kb+1), which is
+// complete after this update: it factorises it on the spot (one wave, potrf_tile_lds), so the next block step starts with
+// its panel solve and the diagonal factorisation costs no launch, no reload and overlaps the other tiles' updates.
 __global__ void __launch_bounds__(256)
-syrk_update_kernel(double* __restrict__ A, int ld, int kb) {
+syrk_update_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info, double* __restrict__ dinv) {
     __shared__ double Pi[64][66];
     __shared__ double Pj[64][66];
     int t = blockIdx.x;
@@ -192,6 +200,21 @@ syrk_update_kernel(double* __restrict__ A, int ld, int kb) {
             acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[n], 0, 0, 0);
         }
     }
+    if (t == 0) {
+        __syncthreads();                                   // every wave is done reading Pi / Pj
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Pi[16 * w + lk + 4 * i][16 * n + lr] = acc[n][i];
+        __syncthreads();
+        if (w == 0) {
+            dinv[bi * 64 + l] = potrf_tile_lds<66>(Pi, l, bi, info);
+            double* D = A + (size_t)(bi * 64) * ld + bi * 64;
+            for (int r = 0; r < 64; ++r)
+                if (l <= r) D[(size_t)r * ld + l] = Pi[r][l];
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -201,13 +224,11 @@ syrk_update_kernel(double* __restrict__ A, int ld, int kb) {
 int launch_cholesky(alabi_gp* gp, hipStream_t s) {
     const int ld = gp->Npad, nb = gp->Npad / 64;
     ALABI_HIP_CHECK(hipMemsetAsync(gp->info, 0, sizeof(int), s));
-    for (int kb = 0; kb < nb; ++kb) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, s, gp->L, ld, kb, gp->info, gp->dinv);
-        int T = nb - kb - 1;
-        if (T > 0) {
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(256), 0, s, gp->L, ld, kb, gp->dinv);
-            hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, s, gp->L, ld, kb);
-        }
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, s, gp->L, ld, 0, gp->info, gp->dinv);
+    for (int kb = 0; kb + 1 < nb; ++kb) {
+        const int T = nb - kb - 1;
+        hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(256), 0, s, gp->L, ld, kb, gp->dinv);
+        hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, s, gp->L, ld, kb, gp->info, gp->dinv);   // + potrf of block kb+1
     }
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;

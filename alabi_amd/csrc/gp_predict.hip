@@ -662,6 +662,162 @@ predict_var_w_kernel(const double* __restrict__ W, const double* __restrict__ Ks
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same product with TWO matrix-core waves per SIMD: 128 queries per workgroup (two neighbouring 64-query K* tiles),
+// eight consumer waves (row group c & 3, query half c >> 2: waves c and c + 4 share a SIMD and cover each other's LDS
+// latency and barrier waits) and four producer waves.  A stage is half a 64 x 64 block of W (32 columns) against 32 rows
+// of both K* tiles, so the LDS holds 2 x (64 x 33 + 32 x 144) doubles = 108 KB and every byte of W read from L2 / HBM feeds
+// twice as many queries as in predict_var_w_kernel.  The accumulation order per output is unchanged (k ascending inside
+// a block, blocks s ascending), so both kernels return the same bits.  tools/micro/mfma_f64_rate: 66-70 TFLOP/s with two
+// MFMA waves per SIMD against 56-59 with one.
+__shared__ double w2_As[2][64][33];
+__shared__ double w2_Vs[2][32][144];
+
+// Uniform values arrive in VGPRs through the call ABI of a noinline function: readfirstlane moves them back to SGPRs so
+// that the stage counters, the address arithmetic and the loop branches are scalar.
+__device__ inline const double* w2_uniform_ptr(const double* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const double*)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __attribute__((noinline)) void
+w2_produce_tile(const double* W_, const double* K0_, const double* K1_, int Npad, int r0, int r1) {
+    const ws_gcptr W = (ws_gcptr)w2_uniform_ptr(W_), K0 = (ws_gcptr)w2_uniform_ptr(K0_), K1 = (ws_gcptr)w2_uniform_ptr(K1_);
+    Npad = __builtin_amdgcn_readfirstlane(Npad); r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
+    const int t8 = threadIdx.x - 512;          // 256 producer threads
+    const int wrow = t8 >> 2, wch = t8 & 3;    // W: row of the block, 8 of its 32 columns (4 x 16-byte loads)
+    const int krow = t8 >> 3, kch = t8 & 7;    // K*: row of the 32, 8 of the 64 queries of each tile (4 + 4 loads)
+    const long long nst = 2 * ((long long)r1 * (r1 + 1) / 2 - (long long)r0 * (r0 + 1) / 2);
+    if (nst <= 0) return;
+    f64x2 pw[2][4], pk[2][8];
+    int kb = r0, sj = 0, hf = 0;               // the next stage to issue; stays on the last stage once it is reached, so
+    const int klast = r1 - 1;                  // that the issue is unconditional (straight-line code keeps vmcnt exact:
+                                               // the wait before a set is written leaves the other set's loads in flight)
+    const size_t wlane = (size_t)wrow * 64 + 8 * wch, klane = (size_t)krow * 64 + 8 * kch;
+#define ALABI_W2_ISSUE(SET)                                                                                          \
+    {                                                                                                                \
+        const ws_gcptr2 Wb_ = (ws_gcptr2)(W + ((size_t)sj * Npad + (size_t)kb * 64) * 64 + 32 * hf + wlane);         \
+        const size_t ko_ = ((size_t)(sj * 64 + 32 * hf)) * 64 + klane;                                               \
+        const ws_gcptr2 Ka_ = (ws_gcptr2)(K0 + ko_), Kb_ = (ws_gcptr2)(K1 + ko_);                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { pw[SET][i] = Wb_[i]; pk[SET][i] = Ka_[i]; pk[SET][4 + i] = Kb_[i]; } \
+        const int adv_ = (kb < klast || sj < kb || hf == 0) ? 1 : 0;                                                 \
+        const int nh_ = hf ^ adv_, carry_ = adv_ & hf;                                                               \
+        const int wrap_ = carry_ & (sj >= kb ? 1 : 0);                                                               \
+        hf = nh_; sj = wrap_ ? 0 : sj + carry_; kb += wrap_;                                                         \
+    }
+#define ALABI_W2_TO_LDS(SET)                                                                                         \
+    {                                                                                                                \
+        double* as_ = &w2_As[SET][wrow][8 * wch];                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { as_[2 * i] = pw[SET][i][0]; as_[2 * i + 1] = pw[SET][i][1]; } \
+        f64x2* va_ = reinterpret_cast<f64x2*>(&w2_Vs[SET][krow][8 * kch]);                                           \
+        f64x2* vb_ = reinterpret_cast<f64x2*>(&w2_Vs[SET][krow][64 + 8 * kch]);                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { va_[i] = pk[SET][i]; vb_[i] = pk[SET][4 + i]; }              \
+    }
+    // Step j (after barrier #j, while the consumers work on stage j): stage j + 1 goes from register set (j + 1) & 1 to LDS
+    // buffer (j + 1) & 1 -- free since barrier #j -- and the set is refilled with stage j + 3; then barrier #(j + 1).
+    // Two steps per loop iteration with no branch between them: the wait before a set is written is vmcnt(12), the other
+    // set's twelve loads stay in flight across the barrier.
+#define ALABI_W2_STEP(SET) { ALABI_W2_TO_LDS(SET) ALABI_W2_ISSUE(SET) __syncthreads(); }
+    ALABI_W2_ISSUE(0)                          // stage 0
+    ALABI_W2_ISSUE(1)                          // stage 1
+    ALABI_W2_TO_LDS(0)
+    ALABI_W2_ISSUE(0)                          // stage 2
+    __syncthreads();                           // barrier #0: stage 0 is in LDS
+    long long j = 0;
+    for (; j + 2 <= nst - 1; j += 2) {
+        ALABI_W2_STEP(1)
+        ALABI_W2_STEP(0)
+    }
+    if (j < nst - 1) ALABI_W2_STEP(1)
+#undef ALABI_W2_TO_LDS
+#undef ALABI_W2_STEP
+#undef ALABI_W2_ISSUE
+}
+
+// Consumer wave c: rows 32 (c & 1) .. +31 of the block row (two 16-row groups), queries 32 (c >> 1) .. +31 (two 16-query
+// groups): two A and two B operands feed four MFMAs per k-step (1.0 LDS read per MFMA instead of 1.25 for a 16 x 64
+// wave tile -- the LDS bandwidth, not the matrix cores, is the tighter budget with eight consumer waves).  Returns the
+// partial sums of squares ss[2 ri + n] of row group ri, query group n (rows lk + 4 i of the row group), accumulated in
+// the same order as predict_var_w_kernel does for its row group 2 (c & 1) + ri.
+__device__ __attribute__((noinline)) v4f64
+w2_consume_tile(int r0, int r1) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int c = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
+    r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
+    const int row0 = 32 * (c & 1), q0 = 32 * (c >> 1);
+    const int lr = lane & 15, lk = lane >> 4;
+    v4f64 ss = v4f64{0.0, 0.0, 0.0, 0.0};
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[ri][n] = v4f64{0.0, 0.0, 0.0, 0.0};
+    int buf = 0;
+    for (int kb = r0; kb < r1; ++kb)
+        for (int sj = 0; sj <= kb; ++sj)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                __syncthreads();               // this stage is in LDS buffer buf
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const double a0 = w2_As[buf][row0 + lr][4 * ks + lk], a1 = w2_As[buf][row0 + 16 + lr][4 * ks + lk];
+                    const double b0 = w2_Vs[buf][4 * ks + lk][q0 + lr], b1 = w2_Vs[buf][4 * ks + lk][q0 + 16 + lr];
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                }
+                buf ^= 1;
+                if (sj == kb && hf == 1) {
+#pragma unroll
+                    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) ss[2 * ri + n] = fma(acc[ri][n][i], acc[ri][n][i], ss[2 * ri + n]);
+                            acc[ri][n] = v4f64{0.0, 0.0, 0.0, 0.0};
+                        }
+                }
+            }
+    return ss;
+}
+
+// grid = (groups of two K* tiles in flight, parts); partial[(tile * parts + part) * 64 + column] as predict_var_w_kernel
+__global__ void __launch_bounds__(768)
+predict_var_w2_kernel(const double* __restrict__ W, const double* __restrict__ Kst, int Npad, long long ntiles, int parts,
+                      double* __restrict__ partial) {
+    __shared__ double red[4][128];             // [row group of the block row][query of the 128]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const int nb = Npad / 64, part = blockIdx.y;
+    int r0, r1;
+    wg_row_range(nb, part, parts, r0, r1);
+    const long long ngroups = (ntiles + 1) / 2;
+    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const long long t0 = 2 * g, t1 = (2 * g + 1 < ntiles) ? 2 * g + 1 : t0;    // an odd last tile is paired with itself
+        __syncthreads();                       // the previous group is completely finished with the LDS stages
+        if (wv >= 8) {
+            w2_produce_tile(W, Kst + (size_t)t0 * Npad * 64, Kst + (size_t)t1 * Npad * 64, Npad, r0, r1);
+        } else {
+            v4f64 ss = w2_consume_tile(r0, r1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {      // q = 2 ri + n
+                ss[q] += __shfl_xor(ss[q], 16, 64);
+                ss[q] += __shfl_xor(ss[q], 32, 64);
+                if (lk == 0) red[2 * (wv & 1) + (q >> 1)][32 * (wv >> 1) + 16 * (q & 1) + lr] = ss[q];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const long long tile = 2 * g + (tid >> 6);
+            if (tile < ntiles)
+                partial[((size_t)tile * parts + part) * 64 + (tid & 63)] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 predict_var_w_final_kernel(const double* __restrict__ partial, int parts, long long M, double amp, double* __restrict__ var) {
     const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -722,8 +878,8 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
         const int TM = (M <= 16LL * n_cu) ? 16 : 64;
         // tiles per chunk: a whole number of rounds over the CUs within ~2 GiB of workspace (at least one round)
         long long chunk_tiles = (2LL << 30) / ((long long)gp->Npad * 64 * 8);     // in 64-query units
-        chunk_tiles = chunk_tiles / n_cu * n_cu;
-        if (chunk_tiles < n_cu) chunk_tiles = n_cu;
+        chunk_tiles = chunk_tiles / (2 * n_cu) * (2 * n_cu);      // predict_var_w2_kernel takes two tiles per workgroup
+        if (chunk_tiles < 2 * n_cu) chunk_tiles = 2 * n_cu;
         if (const char* env = getenv("ALABI_PV_CHUNK_TILES")) { const long long v = atoll(env); if (v > 0) chunk_tiles = v; }   // tests
         long long chunk = chunk_tiles * 64;                                       // queries per chunk
         if (chunk > M) chunk = (M + 63) / 64 * 64;
@@ -765,13 +921,22 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
                 gp->inv_len, amp, gp->mean, gp->kf, gp->ws, mu + m0, TMc)));
             if (use_w) {
                 const int nb = gp->Npad / 64;
+                // two MFMA waves per SIMD (128 queries per workgroup) from 2048 queries on; below that the 64-query
+                // workgroups spread over more CUs (0.24 vs 0.28 ms at 256 queries, N = 2000)
+                const char* e2 = getenv("ALABI_PV_W2");
+                const bool w2 = groups >= 32 && !(e2 && e2[0] == '0');
+                const long long wgs = w2 ? (groups + 1) / 2 : groups;            // workgroups' worth of queries
                 int parts = 1;
-                if (groups < n_cu) { parts = (int)(n_cu / groups); if (parts > nb) parts = nb; if (parts < 1) parts = 1; }
-                const int gx = (int)(groups < n_cu ? groups : n_cu);
+                if (wgs < n_cu) { parts = (int)(n_cu / wgs); if (parts > nb) parts = nb; if (parts < 1) parts = 1; }
+                const int gx = (int)(wgs < n_cu ? wgs : n_cu);
                 int st2 = ensure_small(gp, (size_t)groups * parts * 64 * sizeof(double), s);
                 if (st2 != ALABI_OK) return st2;
-                hipLaunchKernelGGL(predict_var_w_kernel, dim3(gx, parts), dim3(512), 0, s, gp->winv, gp->ws, gp->Npad, groups, parts,
-                                   gp->small);
+                if (w2)
+                    hipLaunchKernelGGL(predict_var_w2_kernel, dim3(gx, parts), dim3(768), 0, s, gp->winv, gp->ws, gp->Npad, groups,
+                                       parts, gp->small);
+                else
+                    hipLaunchKernelGGL(predict_var_w_kernel, dim3(gx, parts), dim3(512), 0, s, gp->winv, gp->ws, gp->Npad, groups,
+                                       parts, gp->small);
                 hipLaunchKernelGGL(predict_var_w_final_kernel, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, s, gp->small, parts, mc,
                                    amp, var + m0);
                 continue;
