@@ -100,6 +100,50 @@ __device__ inline double potrf_tile_lds(double (*Ls)[LD], int lane, int kb, int*
     return my_rinv;
 }
 
+// The same factorisation by a whole 256-thread workgroup: wave 0 runs the slab recurrences, the rank-16 tile updates
+// between slabs (6, 3, 1 tiles) are dealt to the four waves.  Every thread must call it; returns 1/L_ii in wave 0.
+template <int LD>
+__device__ inline double potrf_tile_lds_wg(double (*Ls)[LD], int tid, int kb, int* __restrict__ info) {
+    const int lane = tid & 63, w = tid >> 6;
+    double my_rinv = 1.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c0 = 16 * s;
+        if (w == 0) {
+            double a[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = Ls[lane][c0 + j];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double piv = lane_bcast(a[j], c0 + j);
+                if (!(piv > 0.0)) {  // also true for NaN
+                    if (lane == 0) atomicCAS(info, 0, kb * 64 + c0 + j + 1);
+                    piv = 1.0;
+                }
+                double ljj, rinv;
+                pivot_factors(piv, ljj, rinv);
+                a[j] = (lane == c0 + j) ? ljj : a[j] * rinv;
+                if (lane == c0 + j) my_rinv = rinv;
+#pragma unroll
+                for (int k = j + 1; k < 16; ++k) a[k] = fma(-a[j], lane_bcast(a[j], c0 + k), a[k]);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) Ls[lane][c0 + j] = a[j];
+        }
+        if (s == 3) break;
+        __syncthreads();
+        int t = 0;
+#pragma unroll
+        for (int ti = s + 1; ti < 4; ++ti)
+#pragma unroll
+            for (int tk = s + 1; tk <= ti; ++tk, ++t)
+                if ((t & 3) == w) tile_update_16<LD>(Ls, 16 * ti, 16 * tk, Ls, 16 * ti, Ls, 16 * tk, c0, lane);
+        __syncthreads();
+    }
+    __syncthreads();
+    return my_rinv;
+}
+
 // First diagonal block (the later ones are factorised inside syrk_update_kernel by the workgroup that finishes them).
 __global__ void __launch_bounds__(64)
 potrf_diag_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info, double* __restrict__ dinv) {
@@ -207,12 +251,11 @@ syrk_update_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ inf
 #pragma unroll
             for (int i = 0; i < 4; ++i) Pi[16 * w + lk + 4 * i][16 * n + lr] = acc[n][i];
         __syncthreads();
-        if (w == 0) {
-            dinv[bi * 64 + l] = potrf_tile_lds<66>(Pi, l, bi, info);
-            double* D = A + (size_t)(bi * 64) * ld + bi * 64;
-            for (int r = 0; r < 64; ++r)
-                if (l <= r) D[(size_t)r * ld + l] = Pi[r][l];
-        }
+        const double rinv = potrf_tile_lds_wg<66>(Pi, tid, bi, info);
+        if (w == 0) dinv[bi * 64 + l] = rinv;
+        double* D = A + (size_t)(bi * 64) * ld + bi * 64;
+        for (int r = w; r < 64; r += 4)
+            if (l <= r) D[(size_t)r * ld + l] = Pi[r][l];
         return;
     }
 #pragma unroll

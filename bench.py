@@ -370,7 +370,7 @@ def main():
                                               "frac": pv_tf / FP64_PEAK_TFLOPS, "kernel": "predict_kstar_tile_kernel + predict_var_w2_kernel", "sustained_mfma_peak_measured": {"one_wave_per_simd": 59.1, "two_waves_per_simd": 68.0}}
             ch_tf = extras["cholesky_gflops"] / 1e3
             extras["roofline_cholesky"] = {"bound": "mfma", "achieved": ch_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": ch_tf / FP64_PEAK_TFLOPS, "kernel": "potrf_diag+trsm_panel+syrk_update (N^3/3 flops)",
+                                           "frac": ch_tf / FP64_PEAK_TFLOPS, "kernel": "trsm_panel + syrk_update with fused diagonal potrf (N^3/3 flops)",
                                            "note": "N=2000 is latency-bound on the panel critical path; see DESIGN.md for N=10000"}
             out["extras"] = extras
         if shard_info is not None:
