@@ -614,7 +614,8 @@ class SurrogateModel(object):
 
         obj_opt_method "scan" (default here): ``ncand`` uniform candidates in the scaled box are scored in
         one batched HIP pass (predict mean+variance -> utility -> arg-min), then ``refine`` zoom stages of
-        ``nrefine`` candidates each around the ``ntop`` best.  Any scipy method name keeps
+        ``nrefine`` candidates each around the ``ntop`` best; then the incumbent is polished by
+        L-BFGS-B with the closed-form GPU gradient (``optimizer_kwargs={"polish": maxiter}``, default 30, 0 = off).  Any scipy method name keeps
         the reference's multistart local optimisation with one GP prediction per objective call."""
         t0 = time.time()
         y_best = float(np.max(self._y))
@@ -650,6 +651,13 @@ class SurrogateModel(object):
                     u2 = torch.where(torch.isfinite(o2[3]), o2[3], torch.full_like(o2[3], float("inf")))
                     centers = cloud[torch.topk(-u2, min(ntop, nper)).indices]
                     width = 0.3 * width
+            # optional continuous polish of the incumbent: L-BFGS-B with the closed-form GPU gradient
+            npolish = int(kw.get("polish", 30))
+            if idx >= 0 and npolish > 0:
+                th_p, u_p = ut.polish_point(self.gp, self._y, _thetaN, self._bounds, algorithm=self.algorithm, y_best=y_best,
+                                            maxiter=npolish)
+                if u_p < u_best:
+                    _thetaN, u_best = th_p, u_p
             self.last_acquisition_value = float(u_best) if idx >= 0 else np.nan
             if idx < 0:
                 _thetaN = np.nan

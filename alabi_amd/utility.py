@@ -27,7 +27,7 @@ __all__ = ["agp_utility", "bape_utility", "jones_utility", "assign_utility", "mi
            "prior_sampler", "lnprior_uniform", "lnprior_normal", "prior_transform_uniform", "logsubexp",
            "NewFunctionTransformer", "nlog_scaler", "log_scaler", "no_scaler",
            "utility_scan", "utility_eval_device", "grad_gp_mean_prediction", "grad_gp_var_prediction",
-           "grad_agp_utility", "grad_bape_utility"]
+           "grad_agp_utility", "grad_bape_utility", "utility_value_and_grad", "polish_point"]
 
 
 class NewFunctionTransformer(FunctionTransformer):
@@ -259,6 +259,62 @@ def utility_scan(gp, y, theta, bounds, algorithm="bape", y_best=0.0, return_all=
     best_theta = th[idx].cpu().numpy() if idx >= 0 else np.full(d, np.nan)
     out = (best_theta, float(best_val.value), idx)
     return out + (u, mu, var) if return_all else out
+
+
+def utility_value_and_grad(algorithm, mu, var, dmu, dvar, y_best=0.0, zeta=0.01):
+    """Acquisition value and its TRUE gradient in the query point from (mu, var, dmu[d], dvar[d]) by the chain rule:
+    bape  u = -(2 mu + var + log(e^var - 1)),          du = -2 dmu - (1 + 1/(1 - e^-var)) dvar
+    agp   u = -(mu + 0.5 log(2 pi e var)),             du = -(dmu + dvar / (2 var))
+    jones u = -((mu - yb - zeta) Phi(z) + s phi(z)),   du = -(Phi(z) dmu + phi(z) dvar / (2 s)),  s = sqrt(var)
+    (grad_agp_utility above keeps the reference's literal -(dmu + 0.5 dvar); this one is what an optimiser needs.)
+    Non-finite values (var <= 0 ...) come back as (inf, zeros)."""
+    dmu = np.asarray(dmu, dtype=np.float64); dvar = np.asarray(dvar, dtype=np.float64)
+    bad = (np.inf, np.zeros_like(dmu))
+    with np.errstate(all="ignore"):
+        if algorithm == "bape":
+            if not var > 0.0:
+                return bad
+            u = -((2.0 * mu + var) + logsubexp(var, 0.0))
+            g = -2.0 * dmu - (1.0 - 1.0 / np.expm1(-var)) * dvar
+        elif algorithm == "agp":
+            if not var > 0.0:
+                return bad
+            u = -(mu + 0.5 * np.log(2.0 * np.pi * np.e * var))
+            g = -(dmu + 0.5 * dvar / var)
+        elif algorithm == "jones":
+            if not var > 0.0:
+                return bad
+            sd = np.sqrt(var)
+            z = (mu - y_best - zeta) / sd
+            u = -((mu - y_best - zeta) * norm.cdf(z) + sd * norm.pdf(z))
+            g = -(norm.cdf(z) * dmu + norm.pdf(z) * dvar / (2.0 * sd))
+        else:
+            raise ValueError(algorithm)
+    if not (np.isfinite(u) and np.all(np.isfinite(g))):
+        return bad
+    return float(u), g
+
+
+def polish_point(gp, y, theta0, bounds, algorithm="bape", y_best=0.0, maxiter=30):
+    """L-BFGS-B from ``theta0`` on the acquisition function with value and gradient from ONE device call per evaluation
+    (alabi_gp_predict_grad): the continuous-optimum step of utility.py:1030-1163 on top of a batched scan.
+    The box is shrunk by 1e-9 of its width because the reference's objective is +inf ON the boundary (utility.py:268-275).
+    Returns (theta, u); never worse than the start."""
+    b = np.asarray(bounds, dtype=np.float64)
+    eps = 1e-9 * (b[:, 1] - b[:, 0])
+    box = np.column_stack([b[:, 0] + eps, b[:, 1] - eps])
+    x0 = np.clip(np.asarray(theta0, dtype=np.float64).ravel(), box[:, 0], box[:, 1])
+
+    def fun(x):
+        mu, var, dmu, dvar = gp.predict_grad_device(y, x.reshape(1, -1))
+        u, g = utility_value_and_grad(algorithm, float(mu[0]), float(var[0]), dmu[0].cpu().numpy(), dvar[0].cpu().numpy(), y_best)
+        return (u, g) if np.isfinite(u) else (1e100, np.zeros_like(x))
+
+    u0, _ = fun(x0)
+    res = minimize(fun, x0, jac=True, method="L-BFGS-B", bounds=box, options={"maxiter": int(maxiter), "ftol": 1e-12, "gtol": 1e-8})
+    if np.all(np.isfinite(res.x)) and np.isfinite(res.fun) and res.fun < u0:
+        return res.x, float(res.fun)
+    return x0, float(u0)
 
 
 # ---- multistart local optimiser (reference semantics, one point per objective call) ----------

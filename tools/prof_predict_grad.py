@@ -22,3 +22,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "cpu":
     cfg = make_config("C3"); h = cfg["hyper"]
     o = OracleGP(cfg["d"], h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(cfg["X"]); o._compute_alpha(cfg["y"])
     t0 = time.perf_counter(); uo.grad_gp_var_prediction(cfg["X"][0] + 0.01, o); print("C3 oracle reference-shaped grad var: %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+# one L-BFGS-B polish (30 iterations at most) of a scan incumbent at C3: value + gradient from one device call per evaluation
+from alabi_amd import utility as ut
+cfg = make_config("C3"); h = cfg["hyper"]
+gp = HipGP(cfg["d"], h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); gp.compute(cfg["X"])
+rng = np.random.RandomState(1)
+cand = rng.uniform(cfg["bounds"][:, 0], cfg["bounds"][:, 1], (32768, cfg["d"]))
+th, u0, _ = ut.utility_scan(gp, cfg["y"], cand, cfg["bounds"], algorithm="bape")
+ut.polish_point(gp, cfg["y"], th, cfg["bounds"], "bape", maxiter=30)
+t0 = time.perf_counter(); n = 5
+for _ in range(n): x, u = ut.polish_point(gp, cfg["y"], th, cfg["bounds"], "bape", maxiter=30)
+print("C3 polish from the best of 32768 candidates: %.2f ms, bape %.6f -> %.6f" % ((time.perf_counter() - t0) / n * 1e3, u0, u))
