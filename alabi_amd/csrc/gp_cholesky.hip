@@ -150,9 +150,11 @@ potrf_diag_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info
     __shared__ double Ls[64][65];
     const int lane = threadIdx.x;
     double* Ab = A + (size_t)(kb * 64) * ld + kb * 64;
-    for (int r = 0; r < 64; ++r) Ls[r][lane] = Ab[(size_t)r * ld + lane];   // coalesced rows
+#pragma unroll
+    for (int r = 0; r < 64; ++r) Ls[r][lane] = Ab[(size_t)r * ld + lane];   // coalesced rows, all 64 loads in flight
     __syncthreads();
     dinv[kb * 64 + lane] = potrf_tile_lds<65>(Ls, lane, kb, info);
+#pragma unroll
     for (int r = 0; r < 64; ++r)
         if (lane <= r) Ab[(size_t)r * ld + lane] = Ls[r][lane];
 }
@@ -168,7 +170,9 @@ trsm_panel_kernel(double* __restrict__ A, int ld, int kb, const double* __restri
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const double* Lb = A + (size_t)(kb * 64) * ld + kb * 64;
     double* Bb = A + (size_t)((kb + 1 + blockIdx.x) * 64) * ld + kb * 64;
-    for (int e = tid; e < 4096; e += 256) {
+    #pragma unroll
+    for (int e_ = 0; e_ < 16; ++e_) {
+        const int e = tid + 256 * e_;
         const int r = e >> 6, c = e & 63;
         lkk[r][c] = Lb[(size_t)r * ld + c];
         bs[r][c] = Bb[(size_t)r * ld + c];
@@ -180,15 +184,28 @@ trsm_panel_kernel(double* __restrict__ A, int ld, int kb, const double* __restri
     for (int s = 0; s < 4; ++s) {
         const int c0 = 16 * s;
         if (lane < 16) {
-            double b[16];
+            // every operand of the slab's recurrence is read into registers first (sched_barrier keeps the compiler from
+            // sinking the reads back next to their uses): the chain below then contains no LDS round trip
+            double b[16], dj[16], lreg[120];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) b[j] = bs[row][c0 + j];
+            for (int j = 0; j < 16; ++j) { b[j] = bs[row][c0 + j]; dj[j] = di[c0 + j]; }
+            {
+                int q = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+#pragma unroll
+                    for (int k = j + 1; k < 16; ++k) lreg[q++] = lkk[c0 + k][c0 + j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             // right-looking along the row: two dependent operations per column (scale, first update), the rest fills in
+            {
+                int q = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                b[j] *= di[c0 + j];
+                for (int j = 0; j < 16; ++j) {
+                    b[j] *= dj[j];
 #pragma unroll
-                for (int k = j + 1; k < 16; ++k) b[k] = fma(-b[j], lkk[c0 + k][c0 + j], b[k]);
+                    for (int k = j + 1; k < 16; ++k) b[k] = fma(-b[j], lreg[q++], b[k]);
+                }
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j) bs[row][c0 + j] = b[j];
@@ -199,7 +216,9 @@ trsm_panel_kernel(double* __restrict__ A, int ld, int kb, const double* __restri
         for (int t = s + 1; t < 4; ++t) tile_update_16<65>(bs, 16 * w, 16 * t, bs, 16 * w, lkk, 16 * t, c0, lane);
         __syncthreads();
     }
-    for (int e = tid; e < 4096; e += 256) {
+    #pragma unroll
+    for (int e_ = 0; e_ < 16; ++e_) {
+        const int e = tid + 256 * e_;
         const int r = e >> 6, c = e & 63;
         Bb[(size_t)r * ld + c] = bs[r][c];
     }
@@ -221,7 +240,9 @@ syrk_update_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ inf
     const int tid = threadIdx.x;
     const double* Ai = A + (size_t)(bi * 64) * ld + kb * 64;
     const double* Aj = A + (size_t)(bj * 64) * ld + kb * 64;
-    for (int e = tid; e < 4096; e += 256) {
+    #pragma unroll
+    for (int e_ = 0; e_ < 16; ++e_) {
+        const int e = tid + 256 * e_;
         int r = e >> 6, c = e & 63;
         Pi[r][c] = Ai[(size_t)r * ld + c];
         Pj[r][c] = Aj[(size_t)r * ld + c];
@@ -254,8 +275,11 @@ syrk_update_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ inf
         const double rinv = potrf_tile_lds_wg<66>(Pi, tid, bi, info);
         if (w == 0) dinv[bi * 64 + l] = rinv;
         double* D = A + (size_t)(bi * 64) * ld + bi * 64;
-        for (int r = w; r < 64; r += 4)
+#pragma unroll
+        for (int r0_ = 0; r0_ < 64; r0_ += 4) {
+            const int r = r0_ + w;
             if (l <= r) D[(size_t)r * ld + l] = Pi[r][l];
+        }
         return;
     }
 #pragma unroll

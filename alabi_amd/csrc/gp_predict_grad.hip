@@ -51,18 +51,27 @@ pgrad_v_kernel(const double* __restrict__ W, const double* __restrict__ Xt, int 
         qs[m][k] = (m < M && k < d) ? Xs[(size_t)m * d + k] * inv_len.v[k] : 0.0;
     }
     v4f64 acc = v4f64{0.0, 0.0, 0.0, 0.0};
+    // Block j + 1 (its W tile and the training coordinates of its 64 points) is requested while block j is multiplied: the
+    // loop is a chain of kb + 1 dependent stages and a global round trip per stage would dominate it.  The request is
+    // unconditional (the last block is simply asked for again) so that the waits stay counted.
+    f64x2 wreg[8];
+    double x[D];
+#define ALABI_SMALL_REQUEST(J)                                                                               \
+    {                                                                                                        \
+        const f64x2* Wb_ = reinterpret_cast<const f64x2*>(W + (size_t)(J) * Npad * 64 + (size_t)(kb * 64) * 64); \
+        _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) wreg[e_] = Wb_[tid + 256 * e_];                     \
+        _Pragma("unroll") for (int k = 0; k < D; ++k) x[k] = Xt[(size_t)k * Npad + (J) * 64 + lane];         \
+    }
+    ALABI_SMALL_REQUEST(0)
     for (int j = 0; j <= kb; ++j) {
-        __syncthreads();
-        const double* Wb = W + (size_t)j * Npad * 64 + (size_t)(kb * 64) * 64;
-        for (int e = tid; e < 2048; e += 256) {
-            const int r = e >> 5, c2 = e & 31;
-            *reinterpret_cast<f64x2*>(&Wt[r][2 * c2]) = reinterpret_cast<const f64x2*>(Wb)[e];
-        }
-        {
-            const int n = j * 64 + lane;
-            double x[D];
+        __syncthreads();                                   // the previous block's MFMAs are done with Wt / Ks (and qs is set)
 #pragma unroll
-            for (int k = 0; k < D; ++k) x[k] = Xt[(size_t)k * Npad + n];
+        for (int e_ = 0; e_ < 8; ++e_) {
+            const int e = tid + 256 * e_;
+            *reinterpret_cast<f64x2*>(&Wt[e >> 5][2 * (e & 31)]) = wreg[e_];
+        }
+        {   // K*_j: thread (point p = lane, queries 4w .. 4w+3)
+            const int n = j * 64 + lane;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = 4 * w + i;
@@ -72,11 +81,14 @@ pgrad_v_kernel(const double* __restrict__ W, const double* __restrict__ Xt, int 
                 Ks[lane][m] = (n < N && m < M) ? amp * radial<GENERIC>(r2, kf) : 0.0;
             }
         }
+        const int jn = (j < kb) ? j + 1 : kb;
+        ALABI_SMALL_REQUEST(jn)
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[16 * w + lr][4 * ks + lk], Ks[4 * ks + lk][lr], acc, 0, 0, 0);
     }
+#undef ALABI_SMALL_REQUEST
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[(size_t)(kb * 64 + 16 * w + lk + 4 * i) * 16 + lr] = acc[i];
     double ss = fma(acc[0], acc[0], fma(acc[1], acc[1], fma(acc[2], acc[2], acc[3] * acc[3])));

@@ -24,7 +24,9 @@ trsv_fwd_step_kernel(const double* __restrict__ L, int ld, int kb, const double*
     __shared__ double zs[64];
     const int tid = threadIdx.x;
     const double* Lb = L + (size_t)(kb * 64) * ld + kb * 64;
-    for (int e = tid; e < 4096; e += 256) {
+    #pragma unroll
+    for (int e_ = 0; e_ < 16; ++e_) {
+        const int e = tid + 256 * e_;
         int rr = e >> 6, c = e & 63;
         lkk[rr][c] = (c <= rr) ? Lb[(size_t)rr * ld + c] : 0.0;
     }
@@ -65,7 +67,9 @@ trsv_bwd_step_kernel(const double* __restrict__ L, int ld, int kb, const double*
     __shared__ double part[4][64];
     const int tid = threadIdx.x;
     const double* Lb = L + (size_t)(kb * 64) * ld + kb * 64;
-    for (int e = tid; e < 4096; e += 256) {
+    #pragma unroll
+    for (int e_ = 0; e_ < 16; ++e_) {
+        const int e = tid + 256 * e_;
         int rr = e >> 6, c = e & 63;
         lkk[rr][c] = (c <= rr) ? Lb[(size_t)rr * ld + c] : 0.0;
     }
@@ -134,13 +138,24 @@ trsv_stream_kernel(const double* __restrict__ L, int ld, int nb, const double* _
     __shared__ int abort_s;
     const int tid = threadIdx.x, i = blockIdx.x;
     const double* Lb = L + (size_t)(i * 64) * ld + i * 64;
-    for (int e = tid; e < 4096; e += 256) {
+    #pragma unroll
+    for (int e_ = 0; e_ < 16; ++e_) {
+        const int e = tid + 256 * e_;
         int rr = e >> 6, c = e & 63;
         lkk[rr][c] = (c <= rr) ? Lb[(size_t)rr * ld + c] : 0.0;
     }
     if (tid == 0) abort_s = 0;
     const double di = (tid < 64) ? dinv[i * 64 + tid] : 0.0;
     __syncthreads();
+    // The 64-step substitutions below are chains of dependent operations in ONE wave: an LDS operand inside the chain costs a
+    // full LDS round trip per step (the compiler places each read next to its use).  The lane's row of L_ii (forward) and its
+    // column (backward) are therefore read into registers beforehand, while the hand-offs of the earlier blocks are awaited.
+    double lrow[64], lcol[64];
+    if (tid < 64) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j) { lrow[j] = lkk[tid][j]; lcol[j] = lkk[j][tid]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // ---------------- forward: rhs_i = r_i - sum_{k<i} L[i,k] z_k ; thread = (row, quarter of the 64 columns)
     {
         const int row = tid >> 2, q = tid & 3;
@@ -169,7 +184,7 @@ trsv_stream_kernel(const double* __restrict__ L, int ld, int nb, const double* _
         for (int j = 0; j < 64; ++j) {
             const double zj = lane_bcast(v * di, j);
             if (tid == j) v = zj;
-            if (tid > j) v = fma(-lkk[tid][j], zj, v);
+            if (tid > j) v = fma(-lrow[j], zj, v);
         }
         zi = v;
         __hip_atomic_store(zbuf + i * 64 + tid, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -199,7 +214,7 @@ trsv_stream_kernel(const double* __restrict__ L, int ld, int nb, const double* _
         for (int j = 63; j >= 0; --j) {
             const double aj = lane_bcast(v * di, j);
             if (tid == j) v = aj;
-            if (tid < j) v = fma(-lkk[j][tid], aj, v);
+            if (tid < j) v = fma(-lcol[j], aj, v);
         }
         __hip_atomic_store(abuf + i * 64 + tid, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         alpha[i * 64 + tid] = v;
