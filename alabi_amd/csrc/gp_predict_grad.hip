@@ -133,7 +133,6 @@ pgrad_final_kernel(const double* __restrict__ Xt, const double* __restrict__ alp
                    const double* __restrict__ Xs, int d, DimVec inv_len, double amp, double mean, KernelFn kf,
                    const double* __restrict__ zpart, int parts, const double* __restrict__ partial, int nb,
                    double* __restrict__ mu, double* __restrict__ var, double* __restrict__ dmu, double* __restrict__ dvar) {
-    __shared__ double scratch[16];
     __shared__ double qs[D];
     const int q = blockIdx.x, tid = threadIdx.x;
     if (tid < D) qs[tid] = (tid < d) ? Xs[(size_t)q * d + tid] * inv_len.v[tid] : 0.0;
@@ -141,6 +140,7 @@ pgrad_final_kernel(const double* __restrict__ Xt, const double* __restrict__ alp
     double sm[D], sv[D], smu = 0.0;
 #pragma unroll
     for (int k = 0; k < D; ++k) { sm[k] = 0.0; sv[k] = 0.0; }
+#pragma unroll 2
     for (int i = tid; i < N; i += 256) {
         double df[D], r2 = 0.0;
 #pragma unroll
@@ -156,23 +156,31 @@ pgrad_final_kernel(const double* __restrict__ Xt, const double* __restrict__ alp
 #pragma unroll
         for (int k = 0; k < D; ++k) { sm[k] = fma(ga, df[k], sm[k]); sv[k] = fma(gz, df[k], sv[k]); }
     }
-    smu = block_sum(smu, scratch);
-    if (tid == 0 && mu) mu[q] = mean + smu;
-    if (var) {
-        double s = 0.0;
-        if (tid == 0) {
-            for (int kb = 0; kb < nb; ++kb) s += partial[(size_t)kb * 16 + q];
-            var[q] = amp - s;
-        }
+    // 2 D + 1 sums over the workgroup: one DPP reduction per value inside each wave (result in lane 63), one LDS exchange,
+    // then thread k adds the four wave totals of value k in a fixed order -- one barrier instead of two per value.
+    __shared__ double red[4][2 * D + 1];
+    const int lane = tid & 63, wv = tid >> 6;
+    {
+        const double t = wave_sum_dpp(smu);
+        if (lane == 63) red[wv][2 * D] = t;
     }
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        const double tm = block_sum(sm[k], scratch);
-        const double tv = block_sum(sv[k], scratch);
-        if (tid == 0 && k < d) {
-            dmu[(size_t)q * d + k] = tm * inv_len.v[k];
-            dvar[(size_t)q * d + k] = -2.0 * tv * inv_len.v[k];
-        }
+        const double tm = wave_sum_dpp(sm[k]);
+        const double tv = wave_sum_dpp(sv[k]);
+        if (lane == 63) { red[wv][k] = tm; red[wv][D + k] = tv; }
+    }
+    __syncthreads();
+    if (tid < 2 * D + 1) {
+        const double t = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        if (tid == 2 * D) { if (mu) mu[q] = mean + t; }
+        else if (tid < D) { if (tid < d) dmu[(size_t)q * d + tid] = t * inv_len.v[tid]; }
+        else if (tid - D < d) dvar[(size_t)q * d + (tid - D)] = -2.0 * t * inv_len.v[tid - D];
+    }
+    if (var && tid == 64) {
+        double sacc = 0.0;
+        for (int kb = 0; kb < nb; ++kb) sacc += partial[(size_t)kb * 16 + q];
+        var[q] = amp - sacc;
     }
 }
 
