@@ -32,18 +32,29 @@ append_kcol_kernel(double* __restrict__ Xt, int N, int Npad, const double* __res
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x < D) Xt[(size_t)threadIdx.x * Npad + N] = q[threadIdx.x];
 }
 
-// l = W k for the rows of block rb: W tile-major, W[t][i][c] = L^-1[i][64 t + c] (exact zeros above the diagonal)
+// l = W k for the rows of block rb: W tile-major, W[t][i][c] = L^-1[i][64 t + c] (exact zeros above the diagonal).
+// Thread (row r = tid >> 2, quarter q = tid & 3) owns 16 consecutive columns of its row in every column tile: eight
+// 16-byte loads per tile, four tiles in flight (a lone 8-byte load per iteration left the kernel at 140 GB/s).
 __global__ void __launch_bounds__(256)
 append_lrow_kernel(const double* __restrict__ W, const double* __restrict__ kcol, int N, int Npad, double* __restrict__ lrow) {
-    const int rb = blockIdx.x, w = threadIdx.x >> 6, c = threadIdx.x & 63;
-    for (int r = 0; r < 16; ++r) {
-        const int i = rb * 64 + 16 * w + r;
-        double acc = 0.0;
-        if (i < N)
-            for (int t = 0; t <= rb; ++t) acc = fma(W[((size_t)t * Npad + i) * 64 + c], kcol[64 * t + c], acc);
-        acc = wave_sum_dpp(acc);
-        if (c == 63) lrow[i] = (i < N) ? acc : 0.0;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const int rb = blockIdx.x, r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const int i = rb * 64 + r;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll 4
+    for (int t = 0; t <= rb; ++t) {
+        const f64x2* wp = reinterpret_cast<const f64x2*>(W + ((size_t)t * Npad + i) * 64 + 16 * q);
+        const f64x2* kp = reinterpret_cast<const f64x2*>(kcol + 64 * t + 16 * q);
+        f64x2 wv[8], kv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { wv[e] = wp[e]; kv[e] = kp[e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a0 = fma(wv[e][0], kv[e][0], a0); a1 = fma(wv[e][1], kv[e][1], a1); }
     }
+    double acc = a0 + a1;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (q == 0) lrow[i] = (i < N) ? acc : 0.0;
 }
 
 // pivot of the new row; writes row N of L and dinv[N] when it is positive, reports LAPACK-style info otherwise
@@ -65,19 +76,37 @@ append_pivot_kernel(double* __restrict__ L, double* __restrict__ dinv, const dou
     if (threadIdx.x == 0) { dinv[N] = 1.0 / lnn; scal[0] = lnn; *info = 0; }
 }
 
-// row N of W' for column tile t: -(l^T W)[64 t + c] / l_nn (c < N - 64 t), 1 / l_nn on the diagonal, 0 beyond
+// row N of W' for column tile t: -(l^T W)[64 t + c] / l_nn (c < N - 64 t), 1 / l_nn on the diagonal, 0 beyond.
+// Thread (row group g = tid >> 2 of 64, quarter q) walks the rows 64 t + g, + 64, ... with 16 columns each (eight 16-byte
+// loads per row, two rows in flight); the 64 row groups are then added per column through LDS in a fixed order.
 __global__ void __launch_bounds__(256)
 append_wrow_kernel(double* __restrict__ W, const double* __restrict__ lrow, int N, int Npad, const double* __restrict__ scal) {
-    __shared__ double part[4][64];
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    __shared__ double part[64][65];
     const double lnn = scal[0];
     if (!(lnn > 0.0)) return;                            // the pivot failed: leave W alone
-    const int t = blockIdx.x, g = threadIdx.x >> 6, c = threadIdx.x & 63;
-    double acc = 0.0;
-    for (int i = 64 * t + g; i < N; i += 4) acc = fma(lrow[i], W[((size_t)t * Npad + i) * 64 + c], acc);
-    part[g][c] = acc;
+    const int t = blockIdx.x, g = threadIdx.x >> 2, q = threadIdx.x & 3;
+    double acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+#pragma unroll 2
+    for (int i = 64 * t + g; i < N; i += 64) {
+        const f64x2* wp = reinterpret_cast<const f64x2*>(W + ((size_t)t * Npad + i) * 64 + 16 * q);
+        const double li = lrow[i];
+        f64x2 wv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = wp[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc[2 * e] = fma(li, wv[e][0], acc[2 * e]); acc[2 * e + 1] = fma(li, wv[e][1], acc[2 * e + 1]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[g][16 * q + e] = acc[e];
     __syncthreads();
-    if (g == 0) {
-        const double u = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        double u = 0.0;
+#pragma unroll 8
+        for (int gg = 0; gg < 64; ++gg) u += part[gg][c];
         const int col = 64 * t + c;
         W[((size_t)t * Npad + N) * 64 + c] = (col < N) ? -u / lnn : (col == N ? 1.0 / lnn : 0.0);
     }
