@@ -464,3 +464,33 @@ def test_grad_utilities_against_reference_vectors(torch_gpu, golden_grad):
     ok = fin & (var > 1e-9 * np.exp(float(g["grad_log_amp"])))
     assert ok.sum() >= 15
     assert np.max(np.abs(bape[ok] - g["grad_bape"][ok]) / (np.abs(g["grad_bape"][ok]) + 1.0)) <= 1e-5
+
+
+@pytest.mark.parametrize("N,d,M", [(200, 3, 2048 + 37), (1000, 10, 4096), (777, 5, 20001), (2000, 10, 40000)])
+def test_two_wave_variance_kernel(N, d, M, monkeypatch):
+    """predict_var_w2_kernel (128 queries per workgroup, two MFMA waves per SIMD; taken from 2048 queries on) against the
+    oracle and against the 64-query kernel (ALABI_PV_W2=0): odd tile counts (the last tile is paired with itself), block
+    rows split over several workgroups (few groups), several rounds per workgroup, chunked launches."""
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    X, y, h = make_problem(N, d, 21 + d, log_wn=-9.0)
+    Xs = np.random.RandomState(7).uniform(-3, 3, (M, d))
+    amp = np.exp(h["log_amp"])
+    out = {}
+    for tag, env in (("w2", {"ALABI_PV_W": "1"}), ("w1", {"ALABI_PV_W": "1", "ALABI_PV_W2": "0"}),
+                     ("w2_chunked", {"ALABI_PV_W": "1", "ALABI_PV_CHUNK_TILES": "66"})):
+        for k in ("ALABI_PV_W", "ALABI_PV_W2", "ALABI_PV_CHUNK_TILES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = HipGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+        out[tag] = g.predict(y, Xs, return_var=True)
+    assert np.max(np.abs(out["w2"][1] - out["w1"][1])) <= 1e-12 * amp          # same sums, possibly another split of the rows
+    assert np.max(np.abs(out["w2"][1] - out["w2_chunked"][1])) <= 1e-12 * amp
+    np.testing.assert_array_equal(out["w2"][0], out["w1"][0])
+    o = OracleGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X)
+    sel = np.random.RandomState(1).choice(M, 1500, replace=False)
+    sel[:3] = [M - 1, M - 64, 0]
+    mu_o, var_o = o.predict(y, Xs[sel], return_var=True)
+    assert np.max(np.abs(out["w2"][0][sel] - mu_o) / (np.abs(mu_o) + 1)) <= 1e-9
+    assert np.max(np.abs(out["w2"][1][sel] - var_o)) <= 1e-7 * amp
