@@ -159,6 +159,7 @@ void dev_cache_give(void* p, size_t bytes);         // hand a buffer back (may f
 int dev_alloc_cached(void** p, size_t need, size_t* bytes);   // cache first, then hipMalloc; hipError_t as int
 int launch_factor_inverse(alabi_gp* gp, hipStream_t s);
 int launch_append(alabi_gp* gp, const double* x_new, hipStream_t s);   // gp_append.hip
+int launch_factor_inverse_dnc(alabi_gp* gp, double* R, double* dst, hipStream_t s);   // gp_inverse.hip
 int launch_predict_grad(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var, double* dmu, double* dvar,
                         hipStream_t s);                                  // gp_predict_grad.hip
 int want_winv(alabi_gp* gp, long long M);            // counts the request; 1 when the cached L^-1 should serve it

@@ -1002,7 +1002,7 @@ retile_16_to_64_kernel(const double* __restrict__ src, double* __restrict__ dst,
 int launch_factor_inverse_into(alabi_gp* gp, double* dst, hipStream_t s) {
     const int nb = gp->Npad / 64;
     const size_t need = (size_t)gp->Npad * gp->Npad * sizeof(double);
-    bool fast = dst != gp->ws && nb >= 5;
+    bool fast = dst != gp->ws && nb >= 2;
     if (fast && need > gp->ws_bytes) {
         if (gp->ws) {
             ALABI_HIP_CHECK(hipStreamSynchronize(s));
@@ -1014,6 +1014,9 @@ int launch_factor_inverse_into(alabi_gp* gp, double* dst, hipStream_t s) {
         else gp->ws_bytes = got;
     }
     if (fast) {
+        // recursive block inversion on the matrix cores (gp_inverse.hip); ALABI_WINV_DNC=0 keeps the substitution chains
+        const char* ednc = getenv("ALABI_WINV_DNC");
+        if (!(ednc && ednc[0] == '0')) return launch_factor_inverse_dnc(gp, gp->ws, dst, s);
         int dev = 0, n_cu = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);

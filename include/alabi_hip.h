@@ -83,7 +83,7 @@ int alabi_gp_set_y(alabi_gp* gp, const double* y, void* stream);
  * Xs is [M,d] row-major; mu[M]; var[M] or NULL (mean only).  White noise is not added
  * to var.  var may come out slightly negative from cancellation, as in the reference.
  * The first variance request after a factorisation builds and caches L^-1 (Npad^2 doubles,
- * about 0.7 ms at N = 2000); var = amp - |L^-1 k*|^2 is then a product on the matrix cores.
+ * about 0.25 ms at N = 2000); var = amp - |L^-1 k*|^2 is then a product on the matrix cores.
  * Without room for the cache the blocked forward substitution is used (same values to ~1e-14 amp). */
 int alabi_gp_predict(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var,
                      void* stream);

@@ -494,3 +494,26 @@ def test_two_wave_variance_kernel(N, d, M, monkeypatch):
     mu_o, var_o = o.predict(y, Xs[sel], return_var=True)
     assert np.max(np.abs(out["w2"][0][sel] - mu_o) / (np.abs(mu_o) + 1)) <= 1e-9
     assert np.max(np.abs(out["w2"][1][sel] - var_o)) <= 1e-7 * amp
+
+
+@pytest.mark.parametrize("N", [130, 257, 520, 777, 1000])
+def test_block_recursive_inverse_matches_substitution_chains(N, monkeypatch):
+    """W = L^-1 from the recursive block inversion (gp_inverse.hip; block counts that are not powers of two: 3, 5, 9, 13, 16)
+    gives the same variances as W from the substitution chains (ALABI_WINV_DNC=0) and as the oracle."""
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    d = 4
+    X, y, h = make_problem(N, d, 31, log_wn=-9.0)
+    Xs = np.random.RandomState(2).uniform(-3, 3, (333, d))
+    amp = np.exp(h["log_amp"])
+    out = {}
+    monkeypatch.setenv("ALABI_PV_W", "1")
+    for tag in ("1", "0"):
+        monkeypatch.setenv("ALABI_WINV_DNC", tag)
+        g = HipGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+        out[tag] = g.predict(y, Xs, return_var=True)[1]
+        out[tag + "s"] = g.predict(y, Xs[:7], return_var=True)[1]                   # small-batch kernel on the same W
+    _, var_o = OracleGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X).predict(y, Xs, return_var=True)
+    assert np.max(np.abs(out["1"] - out["0"])) <= 1e-11 * amp
+    assert np.max(np.abs(out["1s"] - out["0s"])) <= 1e-11 * amp
+    assert np.max(np.abs(out["1"] - var_o)) <= 1e-7 * amp
