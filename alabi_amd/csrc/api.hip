@@ -248,11 +248,8 @@ int alabi_gp_predict(alabi_gp* gp, const double* Xs, long long M, double* mu, do
         // substitution stages (the path of per-point objective calls: utility.py:1030-1163, core.py:1441)
         const char* env = getenv("ALABI_PV_SMALL");
         if (M <= 16 && gp->Npad >= 256 && gp->d <= 32 && !(env && env[0] == '0')) {
-            const bool cached = gp->winv && gp->winv_gen == gp->factor_gen;
-            if (cached || gp->Npad <= 2048 || (gp->req_gen == gp->factor_gen && gp->var_requests >= 1)) {
-                (void)want_winv(gp, M);        // count the request
-                return launch_predict_var_small(gp, Xs, (int)M, mu, var, s);
-            }
+            (void)want_winv(gp, M);            // count the request
+            return launch_predict_var_small(gp, Xs, (int)M, mu, var, s);
         }
         return launch_predict_var(gp, Xs, M, mu, var, s);
     }

@@ -857,8 +857,11 @@ int want_winv(alabi_gp* gp, long long M) {
     gp->var_requests++;
     if (envw && envw[0] == '0') return 0;
     if (envw && envw[0] == '1') return 1;
-    const bool cached = gp->winv && gp->winv_gen == gp->factor_gen;
-    return (cached || gp->var_requests >= 2 || (gp->Npad <= 2048 && M <= 16384)) ? 1 : 0;
+    // With the recursive block inversion the cache costs less than the dependency chain of ONE substitution launch
+    // (0.24 vs 0.6 ms at N = 2000, 2.1 vs 3.5 ms at N = 5000), so it is built on the first request; the substitution
+    // kernels remain the fallback when the two Npad^2 buffers cannot be had.
+    (void)M;
+    return 1;
 }
 
 int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var, hipStream_t s) {
@@ -902,10 +905,8 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
         }
         // Product with the cached L^-1 (no dependency between stages, block rows of a tile split over `parts` workgroups
         // when the tiles alone cannot fill the chip); the substitution kernel when there is no room for the cache.
-        // Building the cache costs a latency-bound N^3/3 (0.7 ms at N = 2000, 8 ms at N = 5000): worth it when it is there
-        // already (the gradient built it, or an earlier request), for the second and later requests on one factor, and for
-        // small batches on small factors straight away; a single large scan on a fresh factor goes through the substitution
-        // kernel.  ALABI_PV_W=1 forces the cache, =0 forbids it.
+        // Building the cache (recursive block inversion, 0.24 ms at N = 2000, 2.1 ms at N = 5000) is cheaper than the chain of
+        // one substitution launch, so it is built on the first request.  ALABI_PV_W=0 forbids it.
         int use_w = want_winv(gp, M);
         if (use_w) {
             const int stw = ensure_winv(gp, s);
