@@ -244,10 +244,13 @@ int alabi_gp_predict(alabi_gp* gp, const double* Xs, long long M, double* mu, do
     if (M == 0) return ALABI_OK;
     hipStream_t s = as_stream(stream);
     if (var) {
-        // at most 16 queries: one multiply with the cached L^-1 spread over the block rows instead of 500+ dependent
-        // substitution stages (the path of per-point objective calls: utility.py:1030-1163, core.py:1441)
+        // up to 512 queries: groups of 16 multiply with the cached L^-1, one workgroup per (block row, group), K* evaluated
+        // in place -- no pre-pass (which would fill only M / 64 CUs), no substitution chain (the path of per-point objective
+        // calls: utility.py:1030-1163, core.py:1441, and of medium batches)
         const char* env = getenv("ALABI_PV_SMALL");
-        if (M <= 16 && gp->Npad >= 256 && gp->d <= 32 && !(env && env[0] == '0')) {
+        const char* envm = getenv("ALABI_PV_SMALL_MAX");
+        const long long small_max = envm ? atoll(envm) : 512;
+        if (M <= small_max && gp->Npad >= 256 && gp->d <= 32 && !(env && env[0] == '0')) {
             (void)want_winv(gp, M);            // count the request
             return launch_predict_var_small(gp, Xs, (int)M, mu, var, s);
         }

@@ -1067,6 +1067,11 @@ predict_var_small_kernel(const double* __restrict__ W, const double* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     const int kb = blockIdx.x;
+    // blockIdx.y selects a group of 16 queries (up to 512 queries go through this kernel: one round of nb x groups
+    // workgroups costs less than the K* pre-pass of the tile kernels, which only fills M / 64 CUs)
+    Xs += (size_t)blockIdx.y * 16 * d;
+    M -= (int)blockIdx.y * 16;
+    if (M > 16) M = 16;
     for (int e = tid; e < 16 * D; e += 256) {
         const int m = e / D, k = e % D;
         qs[m][k] = (m < M && k < d) ? Xs[(size_t)m * d + k] * inv_len.v[k] : 0.0;
@@ -1116,15 +1121,16 @@ predict_var_small_kernel(const double* __restrict__ W, const double* __restrict_
     ss += __shfl_xor(ss, 32, 64);
     if (lane < 16) red[w][lane] = ss;
     __syncthreads();
-    if (tid < 16) partial[(size_t)kb * 16 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid < 16) partial[((size_t)blockIdx.y * gridDim.x + kb) * 16 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
 __global__ void __launch_bounds__(64)
 predict_var_small_final_kernel(const double* __restrict__ partial, int nb, int M, double amp, double* __restrict__ var) {
-    const int m = threadIdx.x;
+    const int m = blockIdx.x * 64 + threadIdx.x;           // query; group m / 16, slot m % 16
     if (m >= M) return;
+    const double* pg = partial + (size_t)(m >> 4) * nb * 16 + (m & 15);
     double s = 0.0;
-    for (int kb = 0; kb < nb; ++kb) s += partial[(size_t)kb * 16 + m];
+    for (int kb = 0; kb < nb; ++kb) s += pg[(size_t)kb * 16];
     var[m] = amp - s;
 }
 
@@ -1167,12 +1173,13 @@ int launch_predict_var_small(alabi_gp* gp, const double* Xs, int M, double* mu, 
     int st = ensure_winv(gp, s);
     if (st == ALABI_NOT_COMPUTED) return launch_predict_var(gp, Xs, M, mu, var, s);   // no room: substitution kernel
     if (st != ALABI_OK) return st;
-    if ((st = ensure_small(gp, (size_t)nb * 16 * sizeof(double), s)) != ALABI_OK) return st;
+    const int groups = (M + 15) / 16;
+    if ((st = ensure_small(gp, (size_t)groups * nb * 16 * sizeof(double), s)) != ALABI_OK) return st;
     if ((st = launch_predict_mean(gp, Xs, M, mu, s)) != ALABI_OK) return st;
     const double amp = exp(gp->log_amp);
-    ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_var_small_kernel<D, GENERIC>), dim3(nb),
+    ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_var_small_kernel<D, GENERIC>), dim3(nb, groups),
         dim3(256), 0, s, gp->winv, gp->Xt, gp->N, gp->Npad, Xs, gp->d, M, gp->inv_len, amp, gp->kf, gp->small)));
-    hipLaunchKernelGGL(predict_var_small_final_kernel, dim3(1), dim3(64), 0, s, gp->small, nb, M, amp, var);
+    hipLaunchKernelGGL(predict_var_small_final_kernel, dim3((M + 63) / 64), dim3(64), 0, s, gp->small, nb, M, amp, var);
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }
