@@ -146,6 +146,7 @@ int alabi_gp_destroy(alabi_gp* gp) {
     alabi::dev_cache_give(gp->winv, gp->winv_bytes);
     if (gp->small) (void)hipFree(gp->small);
     if (gp->pgrad) (void)hipFree(gp->pgrad);
+    if (gp->mupart) (void)hipFree(gp->mupart);
     delete gp;
     return ALABI_OK;
 }
@@ -244,12 +245,13 @@ int alabi_gp_predict(alabi_gp* gp, const double* Xs, long long M, double* mu, do
     if (M == 0) return ALABI_OK;
     hipStream_t s = as_stream(stream);
     if (var) {
-        // up to 512 queries: groups of 16 multiply with the cached L^-1, one workgroup per (block row, group), K* evaluated
-        // in place -- no pre-pass (which would fill only M / 64 CUs), no substitution chain (the path of per-point objective
-        // calls: utility.py:1030-1163, core.py:1441, and of medium batches)
+        // up to 128 queries (64 beyond Npad = 2048): groups of 16 multiply with the cached L^-1, one workgroup per (block row,
+        // group), K* evaluated in place -- no pre-pass, no substitution chain (the path of per-point objective calls:
+        // utility.py:1030-1163, core.py:1441, and of small batches); measured cross-over against the tile kernels with the
+        // split K* pre-pass: tools/prof_medium_batch.py
         const char* env = getenv("ALABI_PV_SMALL");
         const char* envm = getenv("ALABI_PV_SMALL_MAX");
-        const long long small_max = envm ? atoll(envm) : 512;
+        const long long small_max = envm ? atoll(envm) : (gp->Npad <= 2048 ? 128 : 64);
         if (M <= small_max && gp->Npad >= 256 && gp->d <= 32 && !(env && env[0] == '0')) {
             (void)want_winv(gp, M);            // count the request
             return launch_predict_var_small(gp, Xs, (int)M, mu, var, s);

@@ -85,6 +85,8 @@ struct alabi_gp {
     int var_requests = 0;     // variance requests seen for the current factor (decides when the cache pays)
     double* small = nullptr;  // [Npad / 64][16] partial sums of the small-batch variance kernel
     size_t small_bytes = 0;
+    double* mupart = nullptr; // partial mean sums of the K* pre-pass when the training points are split over workgroups
+    size_t mupart_bytes = 0;
     double* pgrad = nullptr;  // scratch of the query-gradient path (v, |v|^2 partials, z parts)
     size_t pgrad_bytes = 0;
 };

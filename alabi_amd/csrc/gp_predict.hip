@@ -444,19 +444,24 @@ template <int D, bool GENERIC>
 __global__ void __launch_bounds__(256)
 predict_kstar_tile_kernel(const double* __restrict__ Xt, const double* __restrict__ alpha, int N, int Npad,
                           const double* __restrict__ Xs, int d, long long M, DimVec inv_len, double amp, double mean,
-                          KernelFn kf, double* __restrict__ ws, double* __restrict__ mu, int TM) {
+                          KernelFn kf, double* __restrict__ ws, double* __restrict__ mu, int TM,
+                          double* __restrict__ mu_part, long long mu_stride) {
     __shared__ double xt[D][256];
     __shared__ double al[256];
     __shared__ double part[4][64];
     const int tid = threadIdx.x, c = tid & 63, w = tid >> 6;
     const long long m = (long long)blockIdx.x * 64 + c;
+    // gridDim.y > 1: the training points are split into gridDim.y ranges of whole 256-point stages (few query tiles cannot fill
+    // the chip otherwise); every range writes its K* rows and its part of the mean sum, predict_var_w_final_kernel adds the parts
+    const int stages = (Npad + 255) / 256;
+    const int st_lo = (int)((long long)stages * blockIdx.y / gridDim.y), st_hi = (int)((long long)stages * (blockIdx.y + 1) / gridDim.y);
     // 64 queries per workgroup = 64 / TM variance tiles of TM queries, each [Npad][TM] in the workspace
     double* V = ws + ((size_t)blockIdx.x * (64 / TM) + c / TM) * Npad * TM + (c % TM);
     double q[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) q[k] = (m < M && k < d) ? Xs[m * d + k] * inv_len.v[k] : 0.0;
     double acc = 0.0;
-    for (int n0 = 0; n0 < Npad; n0 += 256) {
+    for (int n0 = st_lo * 256; n0 < st_hi * 256; n0 += 256) {
         __syncthreads();
         const int n = n0 + tid;
 #pragma unroll
@@ -480,7 +485,11 @@ predict_kstar_tile_kernel(const double* __restrict__ Xt, const double* __restric
     }
     part[w][c] = acc;
     __syncthreads();
-    if (tid < 64 && m < M) mu[m] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + mean;
+    if (tid < 64 && m < M) {
+        const double t = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+        if (gridDim.y == 1) mu[m] = t + mean;
+        else mu_part[(size_t)blockIdx.y * mu_stride + m] = t;
+    }
 }
 
 // One workgroup per CU walks over the tiles of TM queries; tile t owns workspace rows ws[t] (K* seeds in, V out).
@@ -819,13 +828,19 @@ predict_var_w2_kernel(const double* __restrict__ W, const double* __restrict__ K
 }
 
 __global__ void __launch_bounds__(256)
-predict_var_w_final_kernel(const double* __restrict__ partial, int parts, long long M, double amp, double* __restrict__ var) {
+predict_var_w_final_kernel(const double* __restrict__ partial, int parts, long long M, double amp, double* __restrict__ var,
+                           const double* __restrict__ mu_part, int nsplit, long long mu_stride, double mean, double* __restrict__ mu) {
     const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     const double* p = partial + (size_t)(m / 64) * parts * 64 + (m % 64);
     double s = 0.0;
     for (int k = 0; k < parts; ++k) s += p[(size_t)k * 64];
     var[m] = amp - s;
+    if (nsplit > 1) {                                      // the mean sum arrived in nsplit ranges of training points
+        double t = 0.0;
+        for (int k = 0; k < nsplit; ++k) t += mu_part[(size_t)k * mu_stride + m];
+        mu[m] = t + mean;
+    }
 }
 
 int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu, hipStream_t s) {
@@ -849,6 +864,18 @@ int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu,
 
 int ensure_winv(alabi_gp* gp, hipStream_t s);
 static int ensure_small(alabi_gp* gp, size_t bytes, hipStream_t s);
+
+static int ensure_mupart(alabi_gp* gp, size_t bytes, hipStream_t s) {
+    if (gp->mupart_bytes >= bytes) return ALABI_OK;
+    if (gp->mupart) {
+        ALABI_HIP_CHECK(hipStreamSynchronize(s));
+        ALABI_HIP_CHECK(hipFree(gp->mupart));
+        gp->mupart = nullptr; gp->mupart_bytes = 0;
+    }
+    ALABI_HIP_CHECK(hipMalloc(&gp->mupart, bytes));
+    gp->mupart_bytes = bytes;
+    return ALABI_OK;
+}
 
 // Should this variance request go through the cached L^-1?  (see the comment in launch_predict_var)
 int want_winv(alabi_gp* gp, long long M) {
@@ -917,9 +944,25 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
             const long long mc = (M - m0 < chunk) ? M - m0 : chunk;
             const long long groups = (mc + 63) / 64;                               // K* workgroups (64 queries each)
             const int TMc = use_w ? 64 : TM;
+            // few query tiles: the K* pre-pass splits the training points over gridDim.y workgroups per tile (W path only)
+            int nsplit = 1;
+            if (use_w && groups < n_cu) {
+                const int stages = (gp->Npad + 255) / 256;
+                nsplit = (int)(n_cu / groups);
+                if (nsplit > stages) nsplit = stages;
+                if (nsplit > 8) nsplit = 8;
+                if (nsplit < 1) nsplit = 1;
+            }
+            const long long mu_stride = (mc + 63) / 64 * 64;
+            double* mu_part = nullptr;
+            if (nsplit > 1) {
+                int stp = ensure_mupart(gp, (size_t)nsplit * mu_stride * sizeof(double), s);
+                if (stp != ALABI_OK) return stp;
+                mu_part = gp->mupart;
+            }
             ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_kstar_tile_kernel<D, GENERIC>),
-                dim3((unsigned)groups), dim3(256), 0, s, gp->Xt, gp->alpha, gp->N, gp->Npad, Xs + m0 * gp->d, gp->d, mc,
-                gp->inv_len, amp, gp->mean, gp->kf, gp->ws, mu + m0, TMc)));
+                dim3((unsigned)groups, nsplit), dim3(256), 0, s, gp->Xt, gp->alpha, gp->N, gp->Npad, Xs + m0 * gp->d, gp->d, mc,
+                gp->inv_len, amp, gp->mean, gp->kf, gp->ws, mu + m0, TMc, mu_part, mu_stride)));
             if (use_w) {
                 const int nb = gp->Npad / 64;
                 // two MFMA waves per SIMD (128 queries per workgroup) from 2048 queries on; below that the 64-query
@@ -939,7 +982,7 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
                     hipLaunchKernelGGL(predict_var_w_kernel, dim3(gx, parts), dim3(512), 0, s, gp->winv, gp->ws, gp->Npad, groups,
                                        parts, gp->small);
                 hipLaunchKernelGGL(predict_var_w_final_kernel, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, s, gp->small, parts, mc,
-                                   amp, var + m0);
+                                   amp, var + m0, mu_part, nsplit, mu_stride, gp->mean, mu + m0);
                 continue;
             }
             const long long tiles_c = (mc + TM - 1) / TM;

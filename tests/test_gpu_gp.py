@@ -311,7 +311,8 @@ def test_predict_variance_paths_agree(monkeypatch):
     amp = np.exp(h["log_amp"])
     # a chunk of 7 tiles splits each tile's block rows over more workgroups than the default launch: same sums, other order
     assert np.max(np.abs(out["default"][1] - out["chunked"][1])) <= 1e-12 * amp
-    np.testing.assert_array_equal(out["default"][0], out["chunked"][0])
+    # (the K* pre-pass splits the training points over more workgroups when a chunk has few tiles: same sum, other grouping)
+    assert np.max(np.abs(out["default"][0] - out["chunked"][0])) <= 1e-13 * (np.max(np.abs(out["default"][0])) + 1)
     assert np.max(np.abs(out["default"][1] - out["legacy"][1])) <= 1e-9 * amp
     assert np.max(np.abs(out["default"][0] - out["legacy"][0])) <= 1e-9 * (np.max(np.abs(out["legacy"][0])) + 1)
     assert np.max(np.abs(out["default"][1] - out["substitution"][1])) <= 1e-9 * amp
