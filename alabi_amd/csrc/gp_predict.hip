@@ -946,9 +946,9 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
             const int TMc = use_w ? 64 : TM;
             // few query tiles: the K* pre-pass splits the training points over gridDim.y workgroups per tile (W path only)
             int nsplit = 1;
-            if (use_w && groups < n_cu) {
+            if (use_w && groups < 2LL * n_cu) {                               // (two workgroups of the pre-pass fit on a CU)
                 const int stages = (gp->Npad + 255) / 256;
-                nsplit = (int)(n_cu / groups);
+                nsplit = (int)(2LL * n_cu / groups);
                 if (nsplit > stages) nsplit = stages;
                 if (nsplit > 8) nsplit = 8;
                 if (nsplit < 1) nsplit = 1;
