@@ -53,7 +53,7 @@ template <int D, bool GENERIC>
 __global__ void __launch_bounds__(256)
 predict_mean_tile_kernel(const double* __restrict__ Xt, const double* __restrict__ alpha, int Npad,
                          const double* __restrict__ Xs, int d, long long M, DimVec inv_len, double amp,
-                         double mean, KernelFn kf, double* __restrict__ mu) {
+                         double mean, KernelFn kf, double* __restrict__ mu, double* __restrict__ mu_part, long long mu_stride) {
     __shared__ double xt[D][256];
     __shared__ double al[256];
     __shared__ double part[4][64];
@@ -63,7 +63,11 @@ predict_mean_tile_kernel(const double* __restrict__ Xt, const double* __restrict
 #pragma unroll
     for (int k = 0; k < D; ++k) q[k] = (m < M && k < d) ? Xs[m * d + k] * inv_len.v[k] : 0.0;
     double acc = 0.0;
-    for (int n0 = 0; n0 < Npad; n0 += 256) {
+    // gridDim.y > 1: whole 256-point stages of the training set are dealt to gridDim.y workgroups per query tile (too few
+    // tiles to fill the chip otherwise); mean_combine_kernel adds the parts in order
+    const int stages = (Npad + 255) / 256;
+    const int st_lo = (int)((long long)stages * blockIdx.y / gridDim.y), st_hi = (int)((long long)stages * (blockIdx.y + 1) / gridDim.y);
+    for (int n0 = st_lo * 256; n0 < st_hi * 256; n0 += 256) {
         __syncthreads();
         const int n = n0 + tid;
 #pragma unroll
@@ -84,7 +88,21 @@ predict_mean_tile_kernel(const double* __restrict__ Xt, const double* __restrict
     }
     part[w][c] = acc;
     __syncthreads();
-    if (tid < 64 && m < M) mu[m] = fma(amp, (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]), mean);
+    if (tid < 64 && m < M) {
+        const double t = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+        if (gridDim.y == 1) mu[m] = fma(amp, t, mean);
+        else mu_part[(size_t)blockIdx.y * mu_stride + m] = t;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+mean_combine_kernel(const double* __restrict__ mu_part, int nsplit, long long mu_stride, long long M, double amp, double mean,
+                    double* __restrict__ mu) {
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    double t = 0.0;
+    for (int k = 0; k < nsplit; ++k) t += mu_part[(size_t)k * mu_stride + m];
+    mu[m] = fma(amp, t, mean);
 }
 
 // IDENT = true turns the same blocked forward substitution into a triangular inversion: the right-hand side of
@@ -843,6 +861,8 @@ predict_var_w_final_kernel(const double* __restrict__ partial, int parts, long l
     }
 }
 
+static int ensure_mupart(alabi_gp* gp, size_t bytes, hipStream_t s);
+
 int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu, hipStream_t s) {
     if (M <= 0) return ALABI_OK;
     const int db = dim_bucket(gp->d);
@@ -854,9 +874,28 @@ int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu,
     } else {
         const long long tiles = (M + 63) / 64;
         if (tiles > 0x7fffffffLL) return ALABI_BAD_ARGUMENT;
-        ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_mean_tile_kernel<D, GENERIC>), dim3((unsigned)tiles), dim3(256), 0, s,
+        int dev = 0, n_cu = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        int nsplit = 1;
+        if (tiles < 2LL * n_cu) {                              // fewer tiles than two per CU: split the training points
+            const int stages = (gp->Npad + 255) / 256;
+            nsplit = (int)(2LL * n_cu / tiles);
+            if (nsplit > stages) nsplit = stages;
+            if (nsplit > 8) nsplit = 8;
+            if (nsplit < 1) nsplit = 1;
+        }
+        const long long mu_stride = tiles * 64;
+        if (nsplit > 1) {
+            int st = ensure_mupart(gp, (size_t)nsplit * mu_stride * sizeof(double), s);
+            if (st != ALABI_OK) return st;
+        }
+        ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_mean_tile_kernel<D, GENERIC>), dim3((unsigned)tiles, nsplit), dim3(256), 0, s,
                                                   gp->Xt, gp->alpha, gp->Npad, Xs, gp->d, M, gp->inv_len, amp,
-                                                  gp->mean, gp->kf, mu)));
+                                                  gp->mean, gp->kf, mu, gp->mupart, mu_stride)));
+        if (nsplit > 1)
+            hipLaunchKernelGGL(mean_combine_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, gp->mupart, nsplit, mu_stride, M, amp,
+                               gp->mean, mu);
     }
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
