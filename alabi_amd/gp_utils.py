@@ -80,44 +80,93 @@ def _score(y_val, y_pred, scoring):
     raise ValueError(f"Unsupported scoring method: {scoring}")
 
 
-def _evaluate_candidate(hyperparams, gp, _theta, _y, y_scaler, k_folds, scoring, rng):
-    """Fold scores of one hyper-parameter vector (gp_utils.py:511-637); np.inf marks a failed fold."""
-    if not np.all(np.isfinite(hyperparams)):
-        return None
-    n = len(_theta)
-    perm = rng.permutation(n)                      # KFold(shuffle=True, random_state=None)
-    folds = np.array_split(perm, k_folds)
-    scores = []
-    gp_fold = copy.deepcopy(gp)
-    for k in range(k_folds):
-        val = np.sort(folds[k])
-        train = np.sort(np.concatenate([folds[j] for j in range(k_folds) if j != k]))
-        try:
+def _fold_score(gp_fold, hyperparams, _theta, _y, train, val, y_scaler, scoring, stream):
+    """One fold: factorise on `train`, predict `val` (gp_utils.py:568-600); runs on its own HIP stream."""
+    import torch
+    try:
+        with torch.cuda.stream(stream):
             gp_fold.set_parameter_vector(hyperparams)
             gp_fold.compute(_theta[train])
             ll = gp_fold.log_likelihood(_y[train])
             if not np.isfinite(ll):
                 raise ValueError("GP log-likelihood is invalid")
             _y_pred = gp_fold.predict(_y[train], _theta[val], return_var=False, return_cov=False)
-            if not np.all(np.isfinite(_y_pred)):
-                raise ValueError("GP predictions contain NaN or Inf values")
-            y_val = y_scaler.inverse_transform(_y[val].reshape(-1, 1)).flatten()
-            y_pred = y_scaler.inverse_transform(_y_pred.reshape(-1, 1)).flatten()
-            scores.append(_score(y_val, y_pred, scoring))
-        except Exception:  # noqa: BLE001
-            scores.append(np.inf)
-    return scores
+        if not np.all(np.isfinite(_y_pred)):
+            raise ValueError("GP predictions contain NaN or Inf values")
+        y_val = y_scaler.inverse_transform(_y[val].reshape(-1, 1)).flatten()
+        y_pred = y_scaler.inverse_transform(_y_pred.reshape(-1, 1)).flatten()
+        return _score(y_val, y_pred, scoring)
+    except Exception:  # noqa: BLE001
+        return np.inf
+
+
+class _FoldWorkers:
+    """k GP copies, k HIP streams and k host threads: the folds of a candidate are independent, each factorisation fills only
+    part of the chip and every call blocks on a read-back, so they are issued concurrently (the reference maps them over a
+    process pool, gp_utils.py:640-700).  ctypes releases the GIL during the library calls; distinct handles are thread-safe.
+    ALABI_CV_THREADS=1 runs the folds one after the other."""
+
+    def __init__(self, gp, k_folds):
+        import os
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        self.k = k_folds
+        self.gps = [copy.deepcopy(gp) for _ in range(k_folds)]
+        nthreads = max(1, min(k_folds, int(os.environ.get("ALABI_CV_THREADS", k_folds))))
+        self.streams = [torch.cuda.Stream() for _ in range(k_folds)] if nthreads > 1 else [torch.cuda.current_stream()] * k_folds
+        self.pool = ThreadPoolExecutor(max_workers=nthreads) if nthreads > 1 else None
+
+    def run(self, hyperparams, _theta, _y, folds, y_scaler, scoring):
+        import torch
+        jobs = []
+        for k in range(self.k):
+            val = np.sort(folds[k])
+            train = np.sort(np.concatenate([folds[j] for j in range(self.k) if j != k]))
+            jobs.append((self.gps[k], hyperparams, _theta, _y, train, val, y_scaler, scoring, self.streams[k]))
+        if self.pool is None:
+            return [_fold_score(*j) for j in jobs]
+        for st in self.streams:
+            st.wait_stream(torch.cuda.current_stream())
+        out = list(self.pool.map(lambda j: _fold_score(*j), jobs))
+        for st in self.streams:
+            torch.cuda.current_stream().wait_stream(st)
+        return out
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
+
+
+def _evaluate_candidate(hyperparams, gp, _theta, _y, y_scaler, k_folds, scoring, rng, workers=None):
+    """Fold scores of one hyper-parameter vector (gp_utils.py:511-637); np.inf marks a failed fold."""
+    if not np.all(np.isfinite(hyperparams)):
+        return None
+    n = len(_theta)
+    perm = rng.permutation(n)                      # KFold(shuffle=True, random_state=None)
+    folds = np.array_split(perm, k_folds)
+    own = workers is None
+    if own:
+        workers = _FoldWorkers(gp, k_folds)
+    try:
+        return workers.run(hyperparams, _theta, _y, folds, y_scaler, scoring)
+    finally:
+        if own:
+            workers.close()
 
 
 def _mean_scores(cands, gp, _theta, _y, y_scaler, k_folds, scoring, rng):
     out = np.full(len(cands), np.inf)
-    for i, hp in enumerate(cands):
-        s = _evaluate_candidate(hp, gp, _theta, _y, y_scaler, k_folds, scoring, rng)
-        if s is not None:
-            s = np.asarray(s)
-            ok = s[np.isfinite(s)]
-            if len(ok):
-                out[i] = np.mean(ok)
+    workers = _FoldWorkers(gp, k_folds)
+    try:
+        for i, hp in enumerate(cands):
+            s = _evaluate_candidate(hp, gp, _theta, _y, y_scaler, k_folds, scoring, rng, workers)
+            if s is not None:
+                s = np.asarray(s)
+                ok = s[np.isfinite(s)]
+                if len(ok):
+                    out[i] = np.mean(ok)
+    finally:
+        workers.close()
     return out
 
 
