@@ -14,6 +14,7 @@ parallel-chain trainer.  Deliberate differences are listed in DESIGN.md ("Differ
 """
 from __future__ import annotations
 
+import copy
 import os
 import pickle
 import time
@@ -430,48 +431,53 @@ class SurrogateModel(object):
             gp = self.gp
             gp.compute(_theta)
 
-            def nll(p_opt):
-                p = self.expand_hyperparameter_vector(p_opt)
-                self.set_hyperparameter_vector(gp, p_opt)
-                v = -gp.log_likelihood(_y, quiet=True)
-                if regularize:
-                    v += gp_utils.regularization_term(p, self.hp_length_indices, amp_0=amp_0, mu_0=mu_0, sigma_0=sigma_0)
-                return v if np.isfinite(v) else 1e25
+            def make_objective(gp):
+                """(nll, grad_nll) bound to one GP handle: restarts run concurrently on their own copies."""
+                def nll(p_opt):
+                    p = self.expand_hyperparameter_vector(p_opt)
+                    self.set_hyperparameter_vector(gp, p_opt)
+                    v = -gp.log_likelihood(_y, quiet=True)
+                    if regularize:
+                        v += gp_utils.regularization_term(p, self.hp_length_indices, amp_0=amp_0, mu_0=mu_0, sigma_0=sigma_0)
+                    return v if np.isfinite(v) else 1e25
 
-            def grad_nll(p_opt):
-                """-d logL/dp from the device's analytic gradient (+ the regulariser's), assembled exactly as the
-                reference does (core.py:1255-1277): with uniform_scales the shared length-scale entry receives the MEAN
-                of the per-dimension gradients."""
-                p = self.expand_hyperparameter_vector(p_opt)
-                self.set_hyperparameter_vector(gp, p_opt)
-                try:
-                    grad_lnlike = -gp.grad_log_likelihood(_y, quiet=True)
-                except (np.linalg.LinAlgError, RuntimeError):
-                    return np.zeros(len(p_opt))
-                if not np.all(np.isfinite(grad_lnlike)):
-                    return np.zeros(len(p_opt))
-                if self.uniform_scales:
-                    gll = np.zeros(len(p_opt))
-                    gll[self.hp_length_index] = np.mean(grad_lnlike[self.hp_length_indices])
-                    gll[self.hp_other_indices] = grad_lnlike[self.hp_other_indices]
-                else:
-                    gll = grad_lnlike
-                if regularize:
-                    reg_grad = gp_utils.regularization_gradient(p, self.hp_length_indices, amp_0=amp_0, mu_0=mu_0,
-                                                                sigma_0=sigma_0)
+                def grad_nll(p_opt):
+                    """-d logL/dp from the device's analytic gradient (+ the regulariser's), assembled exactly as the
+                    reference does (core.py:1255-1277): with uniform_scales the shared length-scale entry receives the MEAN
+                    of the per-dimension gradients."""
+                    p = self.expand_hyperparameter_vector(p_opt)
+                    self.set_hyperparameter_vector(gp, p_opt)
+                    try:
+                        grad_lnlike = -gp.grad_log_likelihood(_y, quiet=True)
+                    except (np.linalg.LinAlgError, RuntimeError):
+                        return np.zeros(len(p_opt))
+                    if not np.all(np.isfinite(grad_lnlike)):
+                        return np.zeros(len(p_opt))
                     if self.uniform_scales:
-                        gll[self.hp_length_index] += np.mean(reg_grad[self.hp_length_indices])
+                        gll = np.zeros(len(p_opt))
+                        gll[self.hp_length_index] = np.mean(grad_lnlike[self.hp_length_indices])
+                        gll[self.hp_other_indices] = grad_lnlike[self.hp_other_indices]
                     else:
-                        gll = gll + reg_grad
-                return gll
+                        gll = grad_lnlike
+                    if regularize:
+                        reg_grad = gp_utils.regularization_gradient(p, self.hp_length_indices, amp_0=amp_0, mu_0=mu_0,
+                                                                    sigma_0=sigma_0)
+                        if self.uniform_scales:
+                            gll[self.hp_length_index] += np.mean(reg_grad[self.hp_length_indices])
+                        else:
+                            gll = gll + reg_grad
+                    return gll
+                return nll, grad_nll
+
+            nll, grad_nll = make_objective(gp)
 
             use_grad = self.gp_opt_method in ("newton-cg", "l-bfgs-b")
             opts = dict(optimizer_kwargs)
             if self.gp_opt_method == "l-bfgs-b":
                 opts = {k: v for k, v in opts.items() if k in ("maxiter", "ftol", "gtol", "maxcor", "maxfun", "maxls")}
 
-            def _run(x0):
-                return op.minimize(fun=nll, x0=x0, jac=grad_nll if use_grad else None, method=self.gp_opt_method,
+            def _run(x0, f=nll, g=grad_nll):
+                return op.minimize(fun=f, x0=x0, jac=g if use_grad else None, method=self.gp_opt_method,
                                    bounds=self.hp_bounds, options=opts)
 
             current = self.get_hyperparameter_vector(gp)
@@ -480,7 +486,28 @@ class SurrogateModel(object):
             else:
                 p0 = ut.prior_sampler(bounds=self.hp_bounds, nsample=self.gp_nopt, sampler="lhs", random_state=self._seed())
                 p0[0] = current
-                res = min((_run(p) for p in p0), key=lambda r: r.fun)
+                nthreads = max(1, min(self.gp_nopt, int(os.environ.get("ALABI_ML_THREADS", self.gp_nopt))))
+                if nthreads <= 1:
+                    res = min((_run(p) for p in p0), key=lambda r: r.fun)
+                else:
+                    # The restarts are independent: each gets its own GP handle, HIP stream and host thread (every objective call
+                    # is a chain of small launches with read-backs that fills only part of the chip; ctypes releases the GIL).
+                    # The reference runs them one after the other (core.py:1287-1305); same optimum, ties broken by start order.
+                    from concurrent.futures import ThreadPoolExecutor
+
+                    def _restart(x0):
+                        g_i = copy.deepcopy(gp)
+                        with torch.cuda.stream(torch.cuda.Stream()):
+                            g_i.compute(_theta)
+                            f_i, d_i = make_objective(g_i)
+                            r = _run(x0, f_i, d_i)
+                            torch.cuda.current_stream().synchronize()
+                        return r
+
+                    torch.cuda.current_stream().synchronize()
+                    with ThreadPoolExecutor(max_workers=nthreads) as pool:
+                        results = list(pool.map(_restart, list(p0)))
+                    res = min(results, key=lambda r: r.fun)
             best = res.x
             if not (np.all(np.isfinite(best)) and np.isfinite(res.fun) and res.fun < 1e25):
                 # e.g. the incumbent lies outside the reference's amplitude box (built from the linear var(y),
