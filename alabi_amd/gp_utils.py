@@ -80,7 +80,7 @@ def _score(y_val, y_pred, scoring):
     raise ValueError(f"Unsupported scoring method: {scoring}")
 
 
-def _fold_score(gp_fold, hyperparams, _theta, _y, train, val, y_scaler, scoring, stream):
+def _fold_score(gp_fold, hyperparams, _theta, _y, train, val, inv, scoring, stream):
     """One fold: factorise on `train`, predict `val` (gp_utils.py:568-600); runs on its own HIP stream."""
     import torch
     try:
@@ -93,48 +93,75 @@ def _fold_score(gp_fold, hyperparams, _theta, _y, train, val, y_scaler, scoring,
             _y_pred = gp_fold.predict(_y[train], _theta[val], return_var=False, return_cov=False)
         if not np.all(np.isfinite(_y_pred)):
             raise ValueError("GP predictions contain NaN or Inf values")
-        y_val = y_scaler.inverse_transform(_y[val].reshape(-1, 1)).flatten()
-        y_pred = y_scaler.inverse_transform(_y_pred.reshape(-1, 1)).flatten()
-        return _score(y_val, y_pred, scoring)
+        return _score(inv(_y[val]), inv(_y_pred), scoring)
     except Exception:  # noqa: BLE001
         return np.inf
 
 
+def _inverse_map(y_scaler):
+    """y_scaler.inverse_transform as a plain function of a 1-D array.  An affine scaler (no_scaler, StandardScaler,
+    MinMaxScaler, ...) is recognised by probing and replaced by a * y + b: sklearn's validation costs 50 us per call, and a
+    CV search would make 1750 of them under the GIL."""
+    probe = np.array([[-1.7], [0.0], [0.9], [3.3]])
+    try:
+        out = np.asarray(y_scaler.inverse_transform(probe), dtype=np.float64).ravel()
+        if np.all(np.isfinite(out)):
+            b = out[1]
+            a = (out[3] - out[0]) / (probe[3, 0] - probe[0, 0])
+            if np.allclose(out, a * probe.ravel() + b, rtol=1e-13, atol=1e-13 * (abs(a) + abs(b) + 1)):
+                return lambda v, a=a, b=b: a * np.asarray(v, dtype=np.float64).ravel() + b
+    except Exception:  # noqa: BLE001
+        pass
+    return lambda v: y_scaler.inverse_transform(np.asarray(v).reshape(-1, 1)).flatten()
+
+
 class _FoldWorkers:
-    """k GP copies, k HIP streams and k host threads: the folds of a candidate are independent, each factorisation fills only
-    part of the chip and every call blocks on a read-back, so they are issued concurrently (the reference maps them over a
-    process pool, gp_utils.py:640-700).  ctypes releases the GIL during the library calls; distinct handles are thread-safe.
-    ALABI_CV_THREADS=1 runs the folds one after the other."""
+    """T GP copies, T HIP streams and T host threads working through (candidate, fold) jobs: the jobs are independent, each
+    factorisation fills only part of the chip and every call blocks on a read-back, so they are issued concurrently (the
+    reference maps them over a process pool, gp_utils.py:640-700).  ctypes releases the GIL during the library calls;
+    distinct handles are thread-safe.  T = ALABI_CV_THREADS (default k, at most 12; more threads only contend for the GIL); 1 runs the jobs one after the other."""
 
     def __init__(self, gp, k_folds):
         import os
+        import queue
         import torch
         from concurrent.futures import ThreadPoolExecutor
         self.k = k_folds
-        self.gps = [copy.deepcopy(gp) for _ in range(k_folds)]
-        nthreads = max(1, min(k_folds, int(os.environ.get("ALABI_CV_THREADS", k_folds))))
-        self.streams = [torch.cuda.Stream() for _ in range(k_folds)] if nthreads > 1 else [torch.cuda.current_stream()] * k_folds
-        self.pool = ThreadPoolExecutor(max_workers=nthreads) if nthreads > 1 else None
+        self.nthreads = max(1, min(12, int(os.environ.get("ALABI_CV_THREADS", k_folds))))
+        self.free = queue.SimpleQueue()
+        for _ in range(self.nthreads):
+            self.free.put((copy.deepcopy(gp), torch.cuda.Stream() if self.nthreads > 1 else torch.cuda.current_stream()))
+        self.pool = ThreadPoolExecutor(max_workers=self.nthreads) if self.nthreads > 1 else None
 
-    def run(self, hyperparams, _theta, _y, folds, y_scaler, scoring):
+    def _job(self, args):
+        res = self.free.get()
+        try:
+            return _fold_score(res[0], *args, res[1])
+        finally:
+            self.free.put(res)
+
+    def run_many(self, jobs):
+        """jobs: (hyperparams, _theta, _y, train, val, inverse y map, scoring) tuples -> scores in the same order"""
         import torch
-        jobs = []
-        for k in range(self.k):
-            val = np.sort(folds[k])
-            train = np.sort(np.concatenate([folds[j] for j in range(self.k) if j != k]))
-            jobs.append((self.gps[k], hyperparams, _theta, _y, train, val, y_scaler, scoring, self.streams[k]))
         if self.pool is None:
-            return [_fold_score(*j) for j in jobs]
-        for st in self.streams:
-            st.wait_stream(torch.cuda.current_stream())
-        out = list(self.pool.map(lambda j: _fold_score(*j), jobs))
-        for st in self.streams:
-            torch.cuda.current_stream().wait_stream(st)
-        return out
+            return [self._job(j) for j in jobs]
+        torch.cuda.current_stream().synchronize()
+        return list(self.pool.map(self._job, jobs))
 
     def close(self):
         if self.pool is not None:
             self.pool.shutdown(wait=True)
+
+
+def _fold_jobs(hyperparams, _theta, _y, folds, y_scaler, scoring, inv=None):
+    k_folds = len(folds)
+    inv = _inverse_map(y_scaler) if inv is None else inv
+    jobs = []
+    for k in range(k_folds):
+        val = np.sort(folds[k])
+        train = np.sort(np.concatenate([folds[j] for j in range(k_folds) if j != k]))
+        jobs.append((hyperparams, _theta, _y, train, val, inv, scoring))
+    return jobs
 
 
 def _evaluate_candidate(hyperparams, gp, _theta, _y, y_scaler, k_folds, scoring, rng, workers=None):
@@ -148,25 +175,38 @@ def _evaluate_candidate(hyperparams, gp, _theta, _y, y_scaler, k_folds, scoring,
     if own:
         workers = _FoldWorkers(gp, k_folds)
     try:
-        return workers.run(hyperparams, _theta, _y, folds, y_scaler, scoring)
+        return workers.run_many(_fold_jobs(hyperparams, _theta, _y, folds, y_scaler, scoring))
     finally:
         if own:
             workers.close()
 
 
 def _mean_scores(cands, gp, _theta, _y, y_scaler, k_folds, scoring, rng):
+    """Mean fold score per candidate.  The fold permutations are drawn first, in candidate order (the random stream is the
+    same as when the candidates are evaluated one after the other), then all (candidate, fold) jobs go to the workers."""
     out = np.full(len(cands), np.inf)
+    n = len(_theta)
+    inv = _inverse_map(y_scaler)
+    jobs, owner = [], []
+    for i, hp in enumerate(cands):
+        if not np.all(np.isfinite(hp)):
+            continue
+        folds = np.array_split(rng.permutation(n), k_folds)
+        jb = _fold_jobs(hp, _theta, _y, folds, y_scaler, scoring, inv)
+        jobs.extend(jb); owner.extend([i] * len(jb))
+    if not jobs:
+        return out
     workers = _FoldWorkers(gp, k_folds)
     try:
-        for i, hp in enumerate(cands):
-            s = _evaluate_candidate(hp, gp, _theta, _y, y_scaler, k_folds, scoring, rng, workers)
-            if s is not None:
-                s = np.asarray(s)
-                ok = s[np.isfinite(s)]
-                if len(ok):
-                    out[i] = np.mean(ok)
+        scores = np.asarray(workers.run_many(jobs), dtype=np.float64)
     finally:
         workers.close()
+    owner = np.asarray(owner)
+    for i in np.unique(owner):
+        s = scores[owner == i]
+        ok = s[np.isfinite(s)]
+        if len(ok):
+            out[i] = np.mean(ok)
     return out
 
 
