@@ -649,7 +649,7 @@ class SurrogateModel(object):
         method = str(self.obj_opt_method).lower()
         kw = dict(optimizer_kwargs or {})
         if method == "scan":
-            ncand = int(kw.get("ncand", 32768))
+            ncand = int(kw.get("ncand", 16384))
             gen = torch.Generator(device=_dev())
             gen.manual_seed(self._seed())
             lo = torch.as_tensor(self._bounds[:, 0], device=_dev())

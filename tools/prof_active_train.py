@@ -12,7 +12,7 @@ sm.init_samples(ntrain=N0)
 t0 = time.perf_counter()
 sm.init_gp(hyperopt_method="ml", gp_nopt=1, optimizer_kwargs={"maxiter": 3})
 print(f"init_gp (ML, 3 iterations, analytic device gradient): {time.perf_counter()-t0:.2f} s")
-for ncand in (32768, 65536, 1_000_000):
+for ncand in (16384, 32768, 65536, 1_000_000):
     sm.active_train(niter=2, algorithm="bape", gp_opt_freq=1000, optimizer_kwargs={"ncand": ncand})
     torch.cuda.synchronize(); t0 = time.perf_counter()
     niter = 10
