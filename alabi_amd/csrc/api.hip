@@ -189,6 +189,17 @@ int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream) {
     return ALABI_OK;
 }
 
+int alabi_gp_fit_predict(alabi_gp* gp, const double* X, int N, const double* y, const double* Xs, long long M, double* mu,
+                         double* nll_out, void* stream) {
+    if (!gp || !y || !nll_out || M < 0 || (M > 0 && (!Xs || !mu))) return ALABI_BAD_ARGUMENT;
+    int st = alabi_gp_compute(gp, X, N, stream);
+    if (st != ALABI_OK) return st;
+    if ((st = alabi_gp_set_y(gp, y, stream)) != ALABI_OK) return st;
+    if ((st = alabi_gp_nll(gp, nll_out, stream)) != ALABI_OK) return st;
+    if (M > 0) st = alabi_gp_predict(gp, Xs, M, mu, nullptr, stream);
+    return st;
+}
+
 int alabi_gp_append(alabi_gp* gp, const double* x_new, void* stream) {
     if (!gp || !x_new) return ALABI_BAD_ARGUMENT;
     if (!gp->computed) return ALABI_NOT_COMPUTED;

@@ -266,6 +266,29 @@ class HipGP:
         self.dirty = False
         return True
 
+    def fit_predict_device(self, x_dev, y_dev, xs_dev):
+        """compute(x) + log_likelihood(y) + predict(y, xs) in ONE library call on device tensors (alabi_gp_fit_predict): the
+        per-fold work of the k-fold CV search (gp_utils.py:568-600).  Returns (log-likelihood, mu[M] device tensor); the
+        log-likelihood is -inf when K is not positive definite (mu is then None)."""
+        n = int(x_dev.shape[0])
+        m = int(xs_dev.shape[0])
+        self._ensure_handle(n)
+        self._push_hyper()
+        self._x_dev, self._x, self._n = x_dev, None, n
+        self._restore = False
+        self._y_set, self._alpha_host, self._y, self._y_key = False, None, None, None
+        mu = torch.empty(m, dtype=torch.float64, device=x_dev.device)
+        out = C.c_double(0.0)
+        st = _lib.lib().alabi_gp_fit_predict(self._handle, _lib.ptr(x_dev), n, _lib.ptr(y_dev), _lib.ptr(xs_dev), m, _lib.ptr(mu),
+                                             C.byref(out), _lib.current_stream())
+        if st == _lib.NOT_PD:
+            self.computed = False
+            return -np.inf, None
+        _lib.check(st, "alabi_gp_fit_predict")
+        self.computed, self.dirty = True, False
+        ll = -out.value
+        return (ll if np.isfinite(ll) else -np.inf), mu
+
     def compute_from(self, prev, x, quiet=False):
         """``compute(x)``; when ``prev`` (another HipGP) holds the factorisation of ``x[:-1]`` with the same kernel
         hyper-parameters, its device handle is taken over and the last row is APPENDED in O(N^2) (alabi_gp_append) instead of

@@ -80,17 +80,18 @@ def _score(y_val, y_pred, scoring):
     raise ValueError(f"Unsupported scoring method: {scoring}")
 
 
-def _fold_score(gp_fold, hyperparams, _theta, _y, train, val, inv, scoring, stream):
-    """One fold: factorise on `train`, predict `val` (gp_utils.py:568-600); runs on its own HIP stream."""
+def _fold_score(gp_fold, hyperparams, theta_dev, y_dev, _y, train_dev, val_dev, val, inv, scoring, stream):
+    """One fold: factorise on `train`, predict `val` (gp_utils.py:568-600) -- one library call on its own HIP stream; the
+    training subset is gathered on the device from the resident full set."""
     import torch
     try:
         with torch.cuda.stream(stream):
             gp_fold.set_parameter_vector(hyperparams)
-            gp_fold.compute(_theta[train])
-            ll = gp_fold.log_likelihood(_y[train])
+            ll, mu = gp_fold.fit_predict_device(theta_dev.index_select(0, train_dev), y_dev.index_select(0, train_dev),
+                                                theta_dev.index_select(0, val_dev))
             if not np.isfinite(ll):
                 raise ValueError("GP log-likelihood is invalid")
-            _y_pred = gp_fold.predict(_y[train], _theta[val], return_var=False, return_cov=False)
+            _y_pred = mu.cpu().numpy()
         if not np.all(np.isfinite(_y_pred)):
             raise ValueError("GP predictions contain NaN or Inf values")
         return _score(inv(_y[val]), inv(_y_pred), scoring)
@@ -141,7 +142,7 @@ class _FoldWorkers:
             self.free.put(res)
 
     def run_many(self, jobs):
-        """jobs: (hyperparams, _theta, _y, train, val, inverse y map, scoring) tuples -> scores in the same order"""
+        """jobs: the argument tuples of _fold_score after the GP and before the stream -> scores in the same order"""
         import torch
         if self.pool is None:
             return [self._job(j) for j in jobs]
@@ -153,14 +154,20 @@ class _FoldWorkers:
             self.pool.shutdown(wait=True)
 
 
-def _fold_jobs(hyperparams, _theta, _y, folds, y_scaler, scoring, inv=None):
+def _fold_jobs(hyperparams, _theta, _y, folds, y_scaler, scoring, inv=None, dev=None):
+    """dev = (theta_dev, y_dev): the full training set resident on the device (uploaded once per search)"""
+    import torch
+    from .gp import _to_dev
     k_folds = len(folds)
     inv = _inverse_map(y_scaler) if inv is None else inv
+    if dev is None:
+        dev = (_to_dev(np.ascontiguousarray(_theta, dtype=np.float64), 2), _to_dev(np.ascontiguousarray(_y, dtype=np.float64)))
     jobs = []
     for k in range(k_folds):
         val = np.sort(folds[k])
         train = np.sort(np.concatenate([folds[j] for j in range(k_folds) if j != k]))
-        jobs.append((hyperparams, _theta, _y, train, val, inv, scoring))
+        idx = torch.as_tensor(np.concatenate([train, val]), device=dev[0].device)
+        jobs.append((hyperparams, dev[0], dev[1], _y, idx[:len(train)], idx[len(train):], val, inv, scoring))
     return jobs
 
 
@@ -187,12 +194,14 @@ def _mean_scores(cands, gp, _theta, _y, y_scaler, k_folds, scoring, rng):
     out = np.full(len(cands), np.inf)
     n = len(_theta)
     inv = _inverse_map(y_scaler)
+    from .gp import _to_dev
+    dev = (_to_dev(np.ascontiguousarray(_theta, dtype=np.float64), 2), _to_dev(np.ascontiguousarray(_y, dtype=np.float64)))
     jobs, owner = [], []
     for i, hp in enumerate(cands):
         if not np.all(np.isfinite(hp)):
             continue
         folds = np.array_split(rng.permutation(n), k_folds)
-        jb = _fold_jobs(hp, _theta, _y, folds, y_scaler, scoring, inv)
+        jb = _fold_jobs(hp, _theta, _y, folds, y_scaler, scoring, inv, dev)
         jobs.extend(jb); owner.extend([i] * len(jb))
     if not jobs:
         return out

@@ -88,6 +88,13 @@ int alabi_gp_set_y(alabi_gp* gp, const double* y, void* stream);
 int alabi_gp_predict(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var,
                      void* stream);
 
+/* One held-out evaluation of a hyper-parameter vector: gp.compute(X) + gp.log_likelihood(y) + gp.predict(y, Xs) as the k-fold
+ * cross-validation of the reference does per fold (alabi/gp_utils.py:568-600) -- the three calls in one, so that a search of
+ * 875 folds does not pay the binding's per-call overhead three times.  nll_out is a host double (-log likelihood); mu[M] on
+ * the device; M may be 0.  Same status codes as the three calls (NOT_POSITIVE_DEFINITE leaves the handle uncomputed). */
+int alabi_gp_fit_predict(alabi_gp* gp, const double* X, int N, const double* y, const double* Xs, long long M,
+                         double* mu, double* nll_out, void* stream);
+
 /* Prediction with gradients with respect to the query point, for the acquisition optimiser:
  * grad_gp_mean_prediction / grad_gp_var_prediction -- alabi/utility.py:558-623, which difference the kernel numerically
  * (utility.py:511-555, step 1e-6) and form K^-1 explicitly (solver.get_inverse(), utility.py:610).  Here
