@@ -247,3 +247,44 @@ def test_scan_polish_with_gpu_gradient(tmp_path):
         u, gr = val(x0)
         fd = np.array([(val(x0 + 1e-6 * e)[0] - val(x0 - 1e-6 * e)[0]) / 2e-6 for e in np.eye(len(x0))])
         assert np.max(np.abs(gr - fd)) <= 1e-5 * (np.max(np.abs(fd)) + 1e-3 * abs(u))
+
+
+def test_cv_and_ml_searches_do_not_depend_on_the_thread_count(tmp_path, monkeypatch):
+    """The k-fold CV search (jobs over k streams / threads, one alabi_gp_fit_predict call per fold) and the ML restarts (one
+    thread per start) return the same hyper-parameters as their sequential forms (ALABI_CV_THREADS=1 / ALABI_ML_THREADS=1)."""
+    from sklearn.preprocessing import StandardScaler
+    from alabi_amd import SurrogateModel
+    from alabi_amd.benchmarks import gaussian_shells_nd
+    g = gaussian_shells_nd(3)
+    out = {}
+    for method, var in (("cv", "ALABI_CV_THREADS"), ("ml", "ALABI_ML_THREADS")):
+        for nthr in ("1", "4"):
+            monkeypatch.setenv(var, nthr)
+            sm = SurrogateModel(lnlike_fn=g["fn"], bounds=g["bounds"], savedir=str(tmp_path), verbose=False, random_state=7, cache=False)
+            sm.init_samples(ntrain=150)
+            sm.init_gp(hyperopt_method=method, y_scaler=StandardScaler(), cv_n_candidates=12, gp_nopt=3,
+                       optimizer_kwargs={"maxiter": 8})
+            out[(method, nthr)] = np.array(sm.gp.get_parameter_vector())
+        monkeypatch.delenv(var, raising=False)
+        np.testing.assert_array_equal(out[(method, "1")], out[(method, "4")])
+
+
+def test_fit_predict_equals_separate_calls():
+    """alabi_gp_fit_predict == compute + log_likelihood + predict (the per-fold body of the CV search)."""
+    import torch
+    from alabi_amd import HipGP
+    from conftest import make_problem
+    X, y, h = make_problem(333, 5, 4)
+    Xs = np.random.RandomState(0).uniform(-3, 3, (77, 5))
+    a = HipGP(5, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"])
+    b = HipGP(5, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"])
+    a.compute(X); ll_a = a.log_likelihood(y); mu_a = a.predict(y, Xs, return_cov=False)
+    dev = lambda v: torch.as_tensor(np.ascontiguousarray(v), device="cuda")  # noqa: E731
+    ll_b, mu_b = b.fit_predict_device(dev(X), dev(y), dev(Xs))
+    assert ll_b == ll_a
+    np.testing.assert_array_equal(mu_b.cpu().numpy(), mu_a)
+    bad = HipGP(5, h["mean"], 5.0, h["log_amp"], h["log_M"])
+    Xd = np.vstack([X[:10], X[:10]])                                    # duplicated rows, tiny nugget: not positive definite
+    bad.set_parameter_vector(np.r_[h["mean"], -40.0, h["log_amp"], h["log_M"]])
+    ll, mu = bad.fit_predict_device(dev(Xd), dev(np.r_[y[:10], y[:10]]), dev(Xs))
+    assert (ll == -np.inf and mu is None) or np.isfinite(ll)           # either rejected as not PD or factorised with rounding luck
