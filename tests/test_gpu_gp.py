@@ -518,3 +518,27 @@ def test_block_recursive_inverse_matches_substitution_chains(N, monkeypatch):
     assert np.max(np.abs(out["1"] - out["0"])) <= 1e-11 * amp
     assert np.max(np.abs(out["1s"] - out["0s"])) <= 1e-11 * amp
     assert np.max(np.abs(out["1"] - var_o)) <= 1e-7 * amp
+
+
+@pytest.mark.parametrize("N,d", [(300, 3), (1000, 10)])
+def test_medium_batches_groups_and_split_prepass(N, d):
+    """17 ... 128 queries go through predict_var_small_kernel in groups of 16 (last group partial); 129 ... 2047 through the tile
+    kernels with the K* pre-pass split over the training points; mean-only batches above 4096 queries through the split
+    predict_mean_tile_kernel + mean_combine_kernel.  All against the oracle."""
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    X, y, h = make_problem(N, d, 41, log_wn=-9.0)
+    g = HipGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+    o = OracleGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X)
+    amp = np.exp(h["log_amp"])
+    rng = np.random.RandomState(9)
+    for M in (17, 40, 128, 129, 700, 1999):
+        Xs = rng.uniform(-3, 3, (M, d))
+        mu, var = g.predict(y, Xs, return_var=True)
+        mu_o, var_o = o.predict(y, Xs, return_var=True)
+        assert np.max(np.abs(mu - mu_o) / (np.abs(mu_o) + 1)) <= 1e-9, M
+        assert np.max(np.abs(var - var_o)) <= 1e-7 * amp, M
+    Xs = rng.uniform(-3, 3, (5003, d))
+    mu = g.predict(y, Xs, return_cov=False)
+    mu_o = o.predict(y, Xs)
+    assert np.max(np.abs(mu - mu_o) / (np.abs(mu_o) + 1)) <= 1e-9
