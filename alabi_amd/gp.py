@@ -215,6 +215,8 @@ class HipGP:
         n_expected = len(self.get_parameter_names(include_frozen))
         if p.size != n_expected:
             raise ValueError(f"dimension mismatch: expected {n_expected} parameters, got {p.size}")
+        if np.array_equal(p, self.get_parameter_vector(include_frozen)):
+            return          # unchanged (optimisers evaluate the objective and its gradient at the same point): keep the factor
         i = 0
         if self.fit_mean or include_frozen:
             self.mean_value = float(p[i]); i += 1
