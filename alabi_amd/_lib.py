@@ -56,6 +56,10 @@ SIGNATURES = {
     "alabi_ens_destroy": (_i, [_vp]),
     "alabi_ens_set_logp_affine": (_i, [_vp, _d, _d]),
     "alabi_ens_set_normal_prior": (_i, [_vp, _pd, _pd]),
+    "alabi_ens_set_logp_map": (_i, [_vp, _i]),
+    "alabi_ens_surrogate": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "alabi_ens_propose": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "alabi_ens_accept": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "alabi_ens_set_stream": (_i, [_vp, _i]),
     "alabi_ens_last_path": (_i, [_vp, _pi]),
     "alabi_ens_lnprob": (_i, [_vp, _vp, _vp, _vp]),

@@ -272,7 +272,7 @@ class SurrogateModel(object):
             return optimized_params
         full = np.ones(len(self.param_names_full))
         names_f, names_o = list(self.param_names_full), self.param_names_optimized
-        for key in ("mean:value", f"{self.kernel_amp_key}:log_constant", "white_noise:value"):
+        for key in ("mean:value", f"{getattr(self, 'kernel_amp_key', 'kernel:k1')}:log_constant", "white_noise:value"):
             if key in names_f and key in names_o:
                 full[names_f.index(key)] = optimized_params[names_o.index(key)]
         for ii in range(self.ndim):
@@ -357,8 +357,8 @@ class SurrogateModel(object):
         self.param_names_optimized = []
         if fit_mean:
             self.param_names_optimized.append("mean:value")
-        self.kernel_amp_key = [x for x in self.param_names_full if "log_constant" in x][0].split(":log_constant")[0]
-        if fit_amp:
+        if fit_amp:      # without the amplitude the model has no log_constant parameter at all (core.py:1057-1059)
+            self.kernel_amp_key = [x for x in self.param_names_full if "log_constant" in x][0].split(":log_constant")[0]
             self.param_names_optimized.append(f"{self.kernel_amp_key}:log_constant")
         if fit_white_noise:
             self.param_names_optimized.append("white_noise:value")
@@ -383,7 +383,8 @@ class SurrogateModel(object):
         log_const = np.log(np.var(_y) / self.ndim) if self.fit_amp else self.kernel.get("log_constant", 0.0)
         return HipGP(self.ndim, mean=np.median(_y), white_noise=self.white_noise, log_constant=log_const,
                      log_M=self.kernel["log_M"], fit_mean=self.fit_mean, fit_white_noise=self.fit_white_noise,
-                     kernel=self.kernel.get("name", "ExpSquaredKernel"), log_alpha=self.kernel.get("log_alpha", 1.0))
+                     kernel=self.kernel.get("name", "ExpSquaredKernel"), log_alpha=self.kernel.get("log_alpha", 1.0),
+                     fit_amp=self.fit_amp)
 
     def _fit_gp(self, _theta=None, _y=None, hyperparameters=None):
         """New GP on (_theta, _y) with the carried hyper-parameter vector, factorised (core.py:1097-1160)."""
@@ -799,47 +800,136 @@ class SurrogateModel(object):
         theta = np.asarray(theta).reshape(1, -1)
         return self.like_fn(theta) + self.prior_fn(theta)
 
+    def find_map(self, theta0=None, prior_fn=None, method="nelder-mead", nRestarts=15, options=None):
+        """Maximum of like_fn + prior_fn (alabi/core.py:2103; called by run_emcee(opt_init=True), core.py:2290-2294).
+
+        The reference declares this entry point and raises NotImplementedError("Not implemented.") in its body, so
+        ``opt_init=True`` cannot run there; here it works: ``nRestarts`` local optimisations (scipy ``method``) of
+        -lnprob from the best points of a batched scan of the posterior (surrogate evaluated on the GPU, 4096 prior
+        draws) and from ``theta0`` if given.  Sets ``self.map_theta`` / ``self.map_lnprob`` and returns the walker start
+        positions run_emcee passes to the sampler: [nwalkers, ndim] in a ball of 1e-3 of the box width around the MAP,
+        clipped into the open box."""
+        prior_fn = prior_fn if prior_fn is not None else getattr(self, "prior_fn", None)
+        if prior_fn is None:
+            prior_fn = partial(ut.lnprior_uniform, bounds=self.bounds)
+        like_fn = getattr(self, "like_fn", None) or self.surrogate_log_likelihood
+        lo, hi = self.bounds[:, 0].astype(float), self.bounds[:, 1].astype(float)
+
+        def lnp(th):
+            th = np.asarray(th, dtype=np.float64).reshape(1, -1)
+            pr = float(np.asarray(prior_fn(th)).reshape(-1)[0])
+            if not np.isfinite(pr):
+                return -np.inf
+            v = float(np.asarray(like_fn(th)).reshape(-1)[0]) + pr
+            return v if np.isfinite(v) else -np.inf
+
+        cand = ut.prior_sampler(bounds=self.bounds, nsample=4096, sampler="uniform", random_state=self._seed())
+        if like_fn == self.surrogate_log_likelihood:     # one batched GPU predict
+            like_c = np.asarray(like_fn(cand), dtype=np.float64).reshape(-1)
+        else:
+            cand = cand[:256]
+            like_c = np.array([float(np.asarray(like_fn(c.reshape(1, -1))).reshape(-1)[0]) for c in cand])
+        post_c = like_c + np.array([float(np.asarray(prior_fn(c.reshape(1, -1))).reshape(-1)[0]) for c in cand])
+        post_c = np.where(np.isfinite(post_c), post_c, -np.inf)
+        starts = [cand[i] for i in np.argsort(-post_c)[:max(int(nRestarts), 1)]]
+        if theta0 is not None:
+            starts.insert(0, np.asarray(theta0, dtype=np.float64).reshape(-1))
+        best_x, best_f = starts[0], lnp(starts[0])
+        eps = 1e-9 * (hi - lo)
+        use_bounds = method.lower() in ("nelder-mead", "l-bfgs-b", "tnc", "powell", "slsqp", "trust-constr")
+        for x0 in starts[:max(int(nRestarts), 1)]:
+            try:
+                res = op.minimize(lambda x: -lnp(x) if np.isfinite(lnp(x)) else 1e25, x0, method=method, options=options,
+                                  bounds=list(zip(lo + eps, hi - eps)) if use_bounds else None)
+            except Exception:  # noqa: BLE001
+                continue
+            f = lnp(res.x)
+            if np.isfinite(f) and f > best_f:
+                best_x, best_f = np.asarray(res.x, dtype=np.float64), f
+        self.map_theta, self.map_lnprob = best_x, best_f
+        nw = int(getattr(self, "nwalkers", 10 * self.ndim))
+        ball = best_x + 1e-3 * (hi - lo) * self._rng.standard_normal((nw, self.ndim))
+        return np.minimum(np.maximum(ball, lo + 1e-9 * (hi - lo)), hi - 1e-9 * (hi - lo))
+
+    def _y_unscale_kind(self):
+        """How y_scaler.inverse_transform acts on a GP mean: ("affine", slope, offset), ("nlog",) / ("log",) for the two
+        non-affine scalers the reference ships (alabi/utility.py:62-71), or None (anything else)."""
+        y_lo, y_hi = float(np.min(self._y)), float(np.max(self._y))
+        aff = _affine_map(self.y_scaler.inverse_transform, np.array([[y_lo - 1.0, y_hi + 1.0]]))
+        if aff is not None and aff[0][0] > 0:
+            return ("affine", float(aff[0][0]), float(aff[1][0]))
+        try:
+            probe = np.linspace(y_lo - 0.5, y_hi + 0.5, 7).reshape(-1, 1)
+            got = np.asarray(self.y_scaler.inverse_transform(probe), dtype=np.float64).reshape(-1)
+            p10 = 10.0 ** probe.reshape(-1)
+            if np.allclose(got, -p10, rtol=1e-12, atol=0.0):
+                return ("nlog",)
+            if np.allclose(got, p10, rtol=1e-12, atol=0.0):
+                return ("log",)
+        except Exception:  # noqa: BLE001
+            pass
+        return None
+
     def run_emcee(self, like_fn=None, prior_fn=None, nwalkers=None, nsteps=int(5e4), sampler_kwargs={}, run_kwargs={},
                   opt_init=False, multi_proc=True, prior_fn_comment=None, burn=None, thin=None, samples_file=None,
                   min_ess=int(1e4)):
-        """Ensemble MCMC on the surrogate posterior, on the GPU (core.py:2108-2414).
+        """Ensemble MCMC on the posterior like_fn + prior_fn, on the GPU (core.py:2108-2414).
 
-        Accelerated case (the reference's default): like_fn=None (GP surrogate) and prior_fn=None (uniform
-        prior on self.bounds).  Arbitrary Python callables cannot run inside the kernel and are rejected."""
-        # prior_fn: None (uniform box) or functools.partial(lnprior_normal, bounds=..., data=...) -- the two priors the
-        # reference ships (utility.py:218, :370); both are fused into the kernel.  Other callables cannot run there.
-        prior_bounds, prior_data = None, None
+        * Fused path (the reference's defaults and the priors it ships): like_fn None / "surrogate" / "gp", prior_fn None,
+          ``partial(lnprior_uniform, bounds=...)`` or ``partial(lnprior_normal, bounds=..., data=...)``, affine theta
+          scaler, y scaler affine or one of the shipped ``nlog_scaler`` / ``log_scaler``: the whole log-probability is
+          evaluated inside the ensemble kernels.
+        * Any other ``prior_fn`` callable (core.py:2253-2280; docstring example :2236-2239): the device proposes and
+          evaluates the surrogate part of every half step, the host adds ``prior_fn(theta)`` per proposal, the device
+          does the accept test (alabi_ens_propose / alabi_ens_accept).
+        * ``like_fn="true"`` or a callable, or scalers that are neither of the above: the same split with the
+          likelihood evaluated on the host as well (walkers then move in the original theta coordinates).
+        ``opt_init=True`` starts the walkers around ``find_map()``.  ``multi_proc`` / ``ncore`` are accepted for
+        signature compatibility: there is no process pool, the parallel axis is the GPU."""
+        # ---- likelihood
+        like_host = None                          # host callable on theta [n,d] -> [n], or None for the device surrogate
+        if like_fn is None or (isinstance(like_fn, str) and like_fn.lower() in ("surrogate", "gp")):
+            self.like_fn_name = "surrogate"
+            self.like_fn = self.surrogate_log_likelihood
+            if not hasattr(self, "gp"):
+                raise NameError("GP has not been trained")
+        elif isinstance(like_fn, str) and like_fn.lower() == "true":
+            self.like_fn_name = "true"
+            self.like_fn = self.true_log_likelihood
+            like_host = self.like_fn
+        elif callable(like_fn):
+            self.like_fn_name = "likelihood"
+            self.like_fn = like_fn
+            like_host = like_fn
+        else:
+            raise ValueError("like_fn must be None, 'surrogate', 'gp', 'true' or a callable")
+        # ---- prior: None (uniform box) or one of the two shipped priors fuse into the kernel; anything else is a host call
+        prior_bounds, prior_data, prior_host = None, None, None
         if prior_fn is not None:
             f = getattr(prior_fn, "func", None)
             kwp = dict(getattr(prior_fn, "keywords", None) or {})
             argp = tuple(getattr(prior_fn, "args", ()) or ())
             name = getattr(f, "__name__", "")
-            if name == "lnprior_uniform" and ("bounds" in kwp or len(argp) >= 1):
+            if name == "lnprior_uniform" and f is ut.lnprior_uniform and ("bounds" in kwp or len(argp) >= 1):
                 prior_bounds = kwp.get("bounds", argp[0] if argp else None)
-            elif name == "lnprior_normal" and (("bounds" in kwp and "data" in kwp) or len(argp) >= 2):
+            elif name == "lnprior_normal" and f is ut.lnprior_normal and (("bounds" in kwp and "data" in kwp) or len(argp) >= 2):
                 prior_bounds = kwp.get("bounds", argp[0] if argp else None)
                 prior_data = kwp.get("data", argp[1] if len(argp) > 1 else None)
             else:
-                raise NotImplementedError("the HIP ensemble sampler fuses the prior into its kernel: prior_fn must be None, "
-                                          "partial(lnprior_uniform, bounds=...) or partial(lnprior_normal, bounds=..., data=...)")
-        if isinstance(like_fn, str) and like_fn.lower() in ("surrogate", "gp"):
-            like_fn = None                       # the reference's explicit spellings of the default (core.py:2118-2124)
-        if like_fn is not None:
-            raise NotImplementedError("the HIP ensemble sampler fuses the surrogate mean into its kernel; like_fn must be "
-                                      "None / 'surrogate' / 'gp' (the true likelihood or a custom callable cannot run there)")
-        if not hasattr(self, "gp"):
-            raise NameError("GP has not been trained")
-        # Affine scalers (no_scaler, MinMaxScaler, StandardScaler, ...) run on the GPU: the ensemble moves in the scaled
-        # coordinates the GP was trained in (the stretch move is affine-invariant, the uniform box maps to self._bounds) and
-        # the log-probability is y_scaler^-1 of the GP mean, an affine map folded into the kernel.  Anything else is rejected.
-        t_aff = _affine_map(self.theta_scaler.transform, self.bounds)
-        y_lo, y_hi = float(np.min(self._y)), float(np.max(self._y))
-        y_aff = _affine_map(self.y_scaler.inverse_transform, np.array([[y_lo - 1.0, y_hi + 1.0]]))
-        if t_aff is None or y_aff is None or not (y_aff[0][0] > 0):
-            raise NotImplementedError("run_emcee on the GPU needs affine theta / y scalers (no_scaler, MinMaxScaler, "
-                                      "StandardScaler, ...)")
+                prior_host = prior_fn
+        # ---- scalers
+        t_aff = _affine_map(self.theta_scaler.transform, self.bounds) if hasattr(self, "theta_scaler") else \
+            (np.ones(self.ndim), np.zeros(self.ndim))
+        y_kind = self._y_unscale_kind() if (like_host is None) else ("affine", 1.0, 0.0)
+        if like_host is None and (t_aff is None or y_kind is None):
+            # exotic scalers: the surrogate is evaluated through surrogate_log_likelihood (batched GPU predict) on the host side
+            like_host = self.surrogate_log_likelihood
+        if like_host is not None:
+            t_aff = (np.ones(self.ndim), np.zeros(self.ndim))     # walkers move in theta itself
+            y_kind = ("affine", 1.0, 0.0)
         t_mult, t_add = t_aff                      # scaled = t_mult * theta + t_add, per dimension
-        logp_affine = (float(y_aff[0][0]), float(y_aff[1][0]))
+        logp_affine = (y_kind[1], y_kind[2]) if y_kind[0] == "affine" else (1.0, 0.0)
+        logp_map = None if y_kind[0] == "affine" else y_kind[0]
         box = self.bounds if prior_bounds is None else np.asarray(prior_bounds, dtype=np.float64).reshape(self.ndim, 2)
         _box = np.sort(box * t_mult[:, None] + t_add[:, None], axis=1)          # the prior box in scaled coordinates
         normal_prior = None
@@ -849,19 +939,48 @@ class SurrogateModel(object):
             # N(m, s) on theta_k is N(mult m + add, |mult| s) on the scaled coordinate; the density stays the theta-space one,
             # so log|mult| per normal coordinate goes back into the log-probability through the constant shift
             normal_prior = (pm * t_mult + t_add, ps * np.abs(t_mult))
-            logp_affine = (logp_affine[0], logp_affine[1] + float(np.sum(np.log(np.abs(t_mult[np.isfinite(pm)])))))
-        self.like_fn_name = "surrogate"
-        self.like_fn = self.surrogate_log_likelihood
+            if logp_map is None:
+                logp_affine = (logp_affine[0], logp_affine[1] + float(np.sum(np.log(np.abs(t_mult[np.isfinite(pm)])))))
+            elif np.any(t_mult[np.isfinite(pm)] != 1.0):
+                prior_host, normal_prior = prior_fn, None        # cannot fold the Jacobian behind a non-affine map: host prior
+        to_theta = lambda c: (np.asarray(c) - t_add) / t_mult  # noqa: E731
+
+        if like_host is not None and prior_fn is not None and prior_data is not None:
+            prior_host, normal_prior = prior_fn, None            # the fused normal prior lives in the device likelihood path
+
+        def _rows(fn):
+            """Host callable on sampler coordinates [n,d] -> [n]: one call per point with a (1, d) argument, exactly what
+            lnprob hands to like_fn / prior_fn (core.py:2097-2098)."""
+            def call(q):
+                th = to_theta(q)
+                return np.array([float(np.asarray(fn(row.reshape(1, -1))).reshape(-1)[0]) for row in th], dtype=np.float64)
+            return call
+
+        def _batched(fn):                                        # the surrogate takes the whole batch in one GPU predict
+            return lambda q: np.asarray(fn(to_theta(q)), dtype=np.float64).reshape(-1)
+        sampler_extra = {}
+        if prior_host is not None or like_host is not None:
+            like_call = None
+            if like_host is not None:
+                like_call = _batched(like_host) if like_host == self.surrogate_log_likelihood else _rows(like_host)
+            sampler_extra = dict(prior_fn=_rows(prior_host) if prior_host is not None else None, like_fn=like_call,
+                                 gate_box=prior_host is None)
         self.prior_fn = partial(ut.lnprior_uniform, bounds=self.bounds) if prior_fn is None else prior_fn
         self.prior_fn_comment = ("Default uniform prior. \nPrior function: ut.prior_fn_uniform\n"
                                  f"\twith bounds {self.bounds}") if prior_fn_comment is None else prior_fn_comment
         self.nwalkers = int(10 * self.ndim) if nwalkers is None else int(nwalkers)
         self.nsteps = int(nsteps)
-        if len(self.training_results["iteration"]) > 0:
+        if hasattr(self, "gp") and len(self.training_results["iteration"]) > 0:
             self.eval_gp_at_iteration(-1)   # makes self.gp carry the latest hyper-parameters / data
-        p0 = ut.prior_sampler(nsample=self.nwalkers, bounds=box, sampler="uniform", random_state=self._seed())
+        if opt_init:
+            p0 = self.find_map(prior_fn=self.prior_fn)           # core.py:2290-2292
+        else:
+            p0 = ut.prior_sampler(nsample=self.nwalkers, bounds=box, sampler="uniform", random_state=self._seed())
         p0 = p0 * t_mult + t_add                   # walkers live in scaled coordinates
-        to_theta = lambda c: (np.asarray(c) - t_add) / t_mult  # noqa: E731
+        if hasattr(self, "gp"):
+            gp_obj, y_obj = self.gp, self._y
+        else:                                      # like_fn="true" before any GP exists: the handle needs an owner only
+            gp_obj, y_obj = HipGP(self.ndim), np.zeros(1)
         if self.verbose:
             print(f"Running emcee-style ensemble on the GPU with {self.nwalkers} walkers for {self.nsteps} steps...")
         all_chains, all_times, accumulated, run_number = [], [], 0, 1
@@ -869,8 +988,8 @@ class SurrogateModel(object):
         kw.setdefault("seed", self._seed())
         while True:
             t0 = time.time()
-            self.emcee_sampler = EnsembleSampler(self.nwalkers, self.ndim, self.gp, self._y, _box,
-                                                 logp_affine=logp_affine, normal_prior=normal_prior, **kw)
+            self.emcee_sampler = EnsembleSampler(self.nwalkers, self.ndim, gp_obj, y_obj, _box, logp_affine=logp_affine,
+                                                 normal_prior=normal_prior, logp_map=logp_map, **sampler_extra, **kw)
             self.emcee_sampler.run_mcmc(p0, self.nsteps, **run_kwargs)
             all_times.append(time.time() - t0)
             cur_iburn, cur_ithin = mcmc_utils.estimate_burnin(self.emcee_sampler, verbose=self.verbose)
@@ -894,7 +1013,10 @@ class SurrogateModel(object):
         self.iburn, self.ithin = cur_iburn, cur_ithin
         self.burn, self.thin = cur_burn, cur_thin
         self.emcee_runtime = sum(all_times)
-        self.emcee_samples_gp = self.emcee_samples
+        if self.like_fn_name == "true":
+            self.emcee_samples_true = self.emcee_samples
+        elif self.like_fn_name == "surrogate":
+            self.emcee_samples_gp = self.emcee_samples
         self.acc_frac = np.mean(self.emcee_sampler.acceptance_fraction)
         self.autcorr_time = np.mean(self.emcee_sampler.get_autocorr_time(tol=0))
         if self.verbose:
@@ -909,8 +1031,11 @@ class SurrogateModel(object):
                 pass
         if samples_file is not None:
             fname = f"{self.savedir}/{samples_file}"
+        elif self.like_fn_name == "true":
+            fname = f"{self.savedir}/emcee_samples_final_{self.like_fn_name}.npz"
         else:
-            it = self.training_results["iteration"][-1] if len(self.training_results["iteration"]) else 0
+            res = getattr(self, "training_results", {"iteration": []})
+            it = res["iteration"][-1] if len(res["iteration"]) else 0
             fname = f"{self.savedir}/emcee_samples_final_{self.like_fn_name}_iter_{it}.npz"
         np.savez(fname, samples=self.emcee_samples)
 

@@ -522,6 +522,13 @@ int alabi_ens_set_logp_affine(alabi_ens* e, double scale, double shift) {
     return ALABI_OK;
 }
 
+int alabi_ens_set_logp_map(alabi_ens* e, int kind) {
+    if (!e || kind < 0 || kind > 2) return ALABI_BAD_ARGUMENT;
+    e->ymap = kind;
+    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }   // captured launches carry the old value
+    return ALABI_OK;
+}
+
 int alabi_ens_set_stream(alabi_ens* e, int enabled) {
     if (!e) return ALABI_BAD_ARGUMENT;
     if (enabled && !(e->hist && e->err)) return ALABI_BAD_ARGUMENT;
@@ -557,7 +564,21 @@ int alabi_ens_lnprob(alabi_ens* e, const double* coords, double* logp, void* str
     if (!e->gp->computed || !e->gp->has_alpha) return ALABI_NOT_COMPUTED;
     int st = sync_consts(e, as_stream(stream));
     if (st != ALABI_OK) return st;
-    return launch_ens_lnprob(e, coords, e->W * e->E, logp, as_stream(stream));
+    return launch_ens_lnprob(e, coords, e->W * e->E, logp, 1, as_stream(stream));
+}
+
+int alabi_ens_surrogate(alabi_ens* e, const double* points, int M, double* like, void* stream) {
+    if (!e || !points || !like || M < 0) return ALABI_BAD_ARGUMENT;
+    if (!e->gp->computed || !e->gp->has_alpha) return ALABI_NOT_COMPUTED;
+    if (M == 0) return ALABI_OK;
+    int st = sync_consts(e, as_stream(stream));
+    if (st != ALABI_OK) return st;
+    // the normal-prior rows are part of the fused log-probability, not of the surrogate: evaluate without them
+    const int hp = e->has_prior; const double pc = e->prior_const;
+    e->has_prior = 0; e->prior_const = 0.0;
+    st = launch_ens_lnprob(e, points, M, like, 0, as_stream(stream));
+    e->has_prior = hp; e->prior_const = pc;
+    return st;
 }
 
 static HalfArgs base_args(alabi_ens* e, double* coords, double* logp) {
@@ -569,7 +590,7 @@ static HalfArgs base_args(alabi_ens* e, double* coords, double* logp) {
     h.amp = e->lp_scale * std::exp(gp->log_amp); h.mean = std::fma(e->lp_scale, gp->mean, e->lp_shift); h.kf = gp->kf;
     h.W = e->W; h.d = e->d; h.n0 = (e->W + 1) / 2;
     h.thin_by = 1; h.run_state = e->run_state;
-    h.has_prior = e->has_prior; h.prior_const = e->prior_const;
+    h.has_prior = e->has_prior; h.prior_const = e->prior_const; h.ymap = e->ymap;
     return h;
 }
 
@@ -688,6 +709,30 @@ int alabi_ens_half_step(alabi_ens* e, double* coords, double* logp, int t, int s
     h.rec = offset_draws(e->draws, (size_t)t * e->W);
     h.local_t = t; h.split = split; h.part_begin = part_begin; h.n_accept = n_accept;
     return launch_ens_half_args(e, h, part_end - part_begin, as_stream(stream));
+}
+
+int alabi_ens_propose(alabi_ens* e, const double* coords, int t, int split, int gate_box, double* q, double* like,
+                      void* stream) {
+    if (!e || !coords || !q || t < 0 || t >= e->drawn_n || (split != 0 && split != 1) || e->E != 1) return ALABI_BAD_ARGUMENT;
+    if (like && (!e->gp->computed || !e->gp->has_alpha)) return ALABI_NOT_COMPUTED;
+    int st = sync_consts(e, as_stream(stream));
+    if (st != ALABI_OK) return st;
+    HalfArgs h = base_args(e, const_cast<double*>(coords), nullptr);
+    const int nS = split == 0 ? h.n0 : e->W - h.n0;
+    h.rec = offset_draws(e->draws, (size_t)t * e->W);
+    h.local_t = t; h.split = split; h.part_begin = 0;
+    return launch_ens_propose(e, h, nS, gate_box, q, like, as_stream(stream));
+}
+
+int alabi_ens_accept(alabi_ens* e, double* coords, double* logp, int t, int split, const double* q, const double* lp_new,
+                     long long* n_accept, void* stream) {
+    if (!e || !coords || !logp || !q || !lp_new || t < 0 || t >= e->drawn_n || (split != 0 && split != 1) || e->E != 1)
+        return ALABI_BAD_ARGUMENT;
+    HalfArgs h = base_args(e, coords, logp);
+    const int nS = split == 0 ? h.n0 : e->W - h.n0;
+    h.rec = offset_draws(e->draws, (size_t)t * e->W);
+    h.local_t = t; h.split = split; h.part_begin = 0; h.n_accept = n_accept;
+    return launch_ens_accept(e, h, nS, q, lp_new, as_stream(stream));
 }
 
 int alabi_ens_step_lists(alabi_ens* e, int t, int* order_out, int* n0, void* stream) {

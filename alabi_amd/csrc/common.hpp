@@ -116,6 +116,7 @@ struct alabi_ens {
     double prior_mean[ALABI_MAX_DIM] = {0}, prior_istd[ALABI_MAX_DIM] = {0};
     double prior_const = 0.0;
     int has_prior = 0;
+    int ymap = 0;             // inverse y scaler applied to the GP mean inside the kernels (0 identity, 1 -10^x, 2 10^x)
     unsigned long long seed = 0;
     double lo[ALABI_MAX_DIM], hi[ALABI_MAX_DIM];
     double* consts = nullptr; // device [3][ALABI_MAX_DIM]: inv_len, lo, hi
@@ -192,6 +193,7 @@ struct HalfArgs {
     int n0, W, d, Npad, split, part_begin, local_t, thin_by;
     int count;                   // proposals in this launch (several per workgroup in ens_half_multi_kernel)
     int has_prior;               // consts rows 3 / 4 hold prior mean and 1 / std
+    int ymap;                    // inverse y scaler on the GP mean: 0 identity, 1 -10^x (nlog_scaler), 2 10^x (log_scaler)
     double prior_const;
     double amp, mean;
     KernelFn kf;
@@ -200,7 +202,9 @@ int launch_ens_draw(alabi_ens* e, int nsteps, double a, hipStream_t s);
 int launch_ens_prep(alabi_ens* e, const int* order, int n0, const double* u_z, const int* partner,
                     const double* u_acc, double a, hipStream_t s);
 int launch_ens_half_args(alabi_ens* e, const HalfArgs& args, int nblocks, hipStream_t s);
-int launch_ens_lnprob(alabi_ens* e, const double* coords, int nwalkers, double* logp, hipStream_t s);
+int launch_ens_lnprob(alabi_ens* e, const double* coords, int nwalkers, double* logp, int gate_box, hipStream_t s);
+int launch_ens_propose(alabi_ens* e, const HalfArgs& args, int nblocks, int gate_box, double* q, double* like, hipStream_t s);
+int launch_ens_accept(alabi_ens* e, const HalfArgs& args, int count, const double* q, const double* lp_new, hipStream_t s);
 int launch_ens_advance(alabi_ens* e, long long n, hipStream_t s);
 bool ens_stream_fits(const alabi_ens* e);
 int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,

@@ -155,6 +155,15 @@ ens_prep_kernel(const int* __restrict__ order, int n0, int W, const double* __re
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+// Inverse of the y scaler applied to the GP mean (alabi/core.py:1483-1502 un-scales every prediction; the two non-affine
+// scalers the reference ships are alabi/utility.py:62-71): 0 identity (affine scalers are folded into amp / mean),
+// 1 nlog_scaler (y = -10^x), 2 log_scaler (y = 10^x).  Evaluated once per proposal by the deciding wave.
+__device__ inline double apply_ymap(double x, int kind) {
+    if (kind == 0) return x;
+    const double v = pow(10.0, x);
+    return kind == 1 ? -v : v;
+}
+
 // Normal-prior term of coordinate `lane` (< d) of a proposal, summed over the wave: lanes >= d contribute 0.
 // consts rows 3 / 4: prior mean, 1 / std (0 where there is no normal prior).  Result valid in every lane.
 __device__ inline double normal_prior_sum(const double* pmean, const double* pistd, int lane, int d, double x) {
@@ -243,6 +252,7 @@ ens_half_kernel(HalfArgs p) {
         part = wave_sum_dpp(part);   // fixed order: bit-reproducible
         const double s = lane_bcast(part, 63);
         lp_new = fma(p.amp, s, p.mean);
+        if (p.ymap) lp_new = apply_ymap(lp_new, p.ymap);
         if (p.has_prior)
             lp_new += normal_prior_sum(p.consts + 3 * ALABI_MAX_DIM, p.consts + 4 * ALABI_MAX_DIM, tid, p.d, q_s[tid]) + p.prior_const;
     } else if (tid >= 64) {
@@ -368,6 +378,7 @@ ens_half_multi_kernel(HalfArgs p) {
             double part = (tid < nw) ? scratch[pp][tid] : 0.0;
             part = wave_sum_dpp(part);
             lp_new = fma(p.amp, lane_bcast(part, 63), p.mean);
+            if (p.ymap) lp_new = apply_ymap(lp_new, p.ymap);
             if (p.has_prior)
                 lp_new += normal_prior_sum(p.consts + 3 * ALABI_MAX_DIM, p.consts + 4 * ALABI_MAX_DIM, tid, p.d, q_s[pp][tid]) +
                           p.prior_const;
@@ -399,7 +410,8 @@ template <int D>
 __global__ void __launch_bounds__(1024)
 ens_lnprob_kernel(const double* __restrict__ coords, int d, const double* __restrict__ Xt,
                   const double* __restrict__ alpha, int Npad, double amp, double mean, KernelFn kf,
-                  const double* __restrict__ consts, int has_prior, double prior_const, double* __restrict__ logp) {
+                  const double* __restrict__ consts, int has_prior, double prior_const, int ymap, int gate_box,
+                  double* __restrict__ logp) {
     __shared__ double qs_s[ALABI_MAX_DIM];
     __shared__ double scratch[16];
     __shared__ double prior_s;
@@ -421,10 +433,69 @@ ens_lnprob_kernel(const double* __restrict__ coords, int d, const double* __rest
                                     : 0.0;
         if (tid == 0) prior_s = pr;
     }
-    const int inb = __syncthreads_and(ok);
+    const int inb = __syncthreads_and(ok) || !gate_box;
     double lp = -INFINITY;
-    if (inb) lp = fma(amp, gp_kernel_dot_block<D>(Xt, alpha, Npad, qs_s, scratch, kf), mean) + prior_s;
+    if (inb) lp = apply_ymap(fma(amp, gp_kernel_dot_block<D>(Xt, alpha, Npad, qs_s, scratch, kf), mean), ymap) + prior_s;
     if (tid == 0) logp[w] = lp;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Generic log-probability path: the reference's lnprob is like_fn(theta) + prior_fn(theta) with ARBITRARY Python
+// callables (alabi/core.py:2073-2100, :2253-2280).  A half step is then split in two launches around the host call:
+//   ens_propose_kernel  one workgroup per proposal of the half: forms q (same arithmetic as ens_half_kernel), writes it
+//                       in list order, and -- when `like` is given -- the surrogate part y_scaler^-1(GP mean) at q
+//                       (box-gated to -inf only if gate_box, i.e. when the prior is the uniform box itself);
+//   (host)              lp_new = like + prior_fn(q)   [or like_fn(q) + prior_fn(q)]
+//   ens_accept_kernel   one thread per proposal: accept test with the record's (d-1) ln z and ln u', state update.
+// The ensemble, the draws and the accept decisions stay on the device; only the proposals of a half step travel.
+template <int D, bool GENERIC>
+__global__ void __launch_bounds__(1024)
+ens_propose_kernel(HalfArgs p, int gate_box, double* __restrict__ q_out, double* __restrict__ like_out) {
+    __shared__ double qs_s[ALABI_MAX_DIM];
+    __shared__ double scratch[16];
+    const int tid = threadIdx.x;
+    const size_t pos = (size_t)(p.split ? p.n0 : 0) + p.part_begin + blockIdx.x;
+    const int w = p.rec.order[pos];
+    if (w < 0) {                                       // inert record: a NaN proposal is rejected by the accept kernel
+        if (tid < p.d) q_out[(size_t)blockIdx.x * p.d + tid] = __longlong_as_double(0x7FF8000000000000ll);
+        if (tid == 0 && like_out) like_out[blockIdx.x] = -INFINITY;
+        return;
+    }
+    const int cw = p.rec.cw[pos];
+    const double zz = p.rec.zz[pos];
+    int ok = 1;
+    if (tid < D) {
+        double qv = 0.0;
+        if (tid < p.d) {
+            const double cv = p.coords[(size_t)cw * p.d + tid];
+            const double sv = p.coords[(size_t)w * p.d + tid];
+            qv = cv - (cv - sv) * zz;
+            ok = (qv > p.consts[ALABI_MAX_DIM + tid]) && (qv < p.consts[2 * ALABI_MAX_DIM + tid]);
+            q_out[(size_t)blockIdx.x * p.d + tid] = qv;
+            qv *= p.consts[tid];
+        }
+        qs_s[tid] = qv;
+    }
+    const int inb = __syncthreads_and(ok) || !gate_box;
+    if (!like_out) return;
+    double lp = -INFINITY;
+    if (inb) lp = apply_ymap(fma(p.amp, gp_kernel_dot_block<D, GENERIC>(p.Xt, p.alpha, p.Npad, qs_s, scratch, p.kf), p.mean), p.ymap);
+    if (tid == 0) like_out[blockIdx.x] = lp;
+}
+
+__global__ void __launch_bounds__(256)
+ens_accept_kernel(HalfArgs p, int count, const double* __restrict__ q, const double* __restrict__ lp_new) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const size_t pos = (size_t)(p.split ? p.n0 : 0) + p.part_begin + i;
+    const int w = p.rec.order[pos];
+    if (w < 0) return;
+    const double lpn = lp_new[i], lpo = p.logp[w];
+    if (p.rec.lnfac[pos] + lpn - lpo > p.rec.lnu[pos]) {      // false for NaN
+        for (int k = 0; k < p.d; ++k) p.coords[(size_t)w * p.d + k] = q[(size_t)i * p.d + k];
+        p.logp[w] = lpn;
+        if (p.n_accept) p.n_accept[w] += 1;
+    }
 }
 
 __global__ void ens_advance_kernel(long long* run_state, long long n) {
@@ -769,6 +840,7 @@ ens_hist_chain_kernel(const unsigned long long* __restrict__ hist, int K, int WT
 static int ens_stream_ppt(const alabi_ens* e) {
     const int T = e->threads, half = e->gp->Npad / 2, db = dim_bucket(e->d);
     if ((T != 256 && T != 512) || e->d > 61 || db < 0 || db > 16) return 0;
+    if (e->ymap != 0) return 0;   // non-affine y scalers (pow) run on the launch-per-half-step path: this kernel has no VGPR to spare
     const int ppt = (half + T - 1) / T;
     const bool generic = e->gp->kf.type != 0;
     int max_db = 0;
@@ -885,13 +957,29 @@ int launch_ens_half_args(alabi_ens* e, const HalfArgs& args_in, int nblocks, hip
     return ALABI_OK;
 }
 
-int launch_ens_lnprob(alabi_ens* e, const double* coords, int nwalkers, double* logp, hipStream_t s) {
+int launch_ens_lnprob(alabi_ens* e, const double* coords, int nwalkers, double* logp, int gate_box, hipStream_t s) {
     const int db = dim_bucket(e->d);
     alabi_gp* gp = e->gp;
     ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(ens_lnprob_kernel<D>, dim3(nwalkers), dim3(e->threads), 0, s, coords, e->d,
                                               gp->Xt, gp->alpha, gp->Npad, e->lp_scale * exp(gp->log_amp),
                                               fma(e->lp_scale, gp->mean, e->lp_shift), gp->kf, e->consts, e->has_prior,
-                                              e->prior_const, logp));
+                                              e->prior_const, e->ymap, gate_box, logp));
+    ALABI_LAUNCH_CHECK();
+    return ALABI_OK;
+}
+
+int launch_ens_propose(alabi_ens* e, const HalfArgs& args, int nblocks, int gate_box, double* q, double* like, hipStream_t s) {
+    if (nblocks <= 0) return ALABI_OK;
+    const int db = dim_bucket(e->d);
+    ALABI_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(e->gp->kf.type, hipLaunchKernelGGL((ens_propose_kernel<D, GENERIC>), dim3(nblocks),
+                                                                                    dim3(e->threads), 0, s, args, gate_box, q, like)));
+    ALABI_LAUNCH_CHECK();
+    return ALABI_OK;
+}
+
+int launch_ens_accept(alabi_ens* e, const HalfArgs& args, int count, const double* q, const double* lp_new, hipStream_t s) {
+    if (count <= 0) return ALABI_OK;
+    hipLaunchKernelGGL(ens_accept_kernel, dim3((count + 255) / 256), dim3(256), 0, s, args, count, q, lp_new);
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

@@ -11,6 +11,7 @@
 // kernel and the steps are ordered by the stream.  2 N^2 flops, latency bound: once per refit.
 #include <cstdlib>
 
+#include <atomic>
 #include "gp_device.hpp"
 
 namespace alabi {
@@ -261,7 +262,12 @@ int launch_alpha(alabi_gp* gp, hipStream_t s) {
     hipLaunchKernelGGL(residual_kernel, dim3((gp->Npad + 255) / 256), dim3(256), 0, s, gp->y, gp->N,
                        gp->Npad, gp->mean, r);
     const char* env = getenv("ALABI_TRSV_STREAM");
-    if (nb <= 200 && gp->flags && !(env && env[0] == '0')) {
+    // A time-out is remembered process-wide for a while (concurrent solves from the CV threads can starve each other of
+    // CUs: every later set_y would otherwise burn the whole spin budget again before falling back).
+    static std::atomic<int> stream_penalty{0};
+    const bool penalised = stream_penalty.load(std::memory_order_relaxed) > 0;
+    if (penalised) stream_penalty.fetch_sub(1, std::memory_order_relaxed);
+    if (nb <= 200 && gp->flags && !penalised && !(env && env[0] == '0')) {
         // single-launch dataflow solve (all nb workgroups resident); z / alpha hand-off buffers live in `work`
         unsigned long long* zbuf = reinterpret_cast<unsigned long long*>(z);
         unsigned long long* abuf = reinterpret_cast<unsigned long long*>(gp->work2);
@@ -275,7 +281,9 @@ int launch_alpha(alabi_gp* gp, hipStream_t s) {
         ALABI_HIP_CHECK(hipMemcpyAsync(&flag, gp->flags, sizeof(int), hipMemcpyDeviceToHost, s));
         ALABI_HIP_CHECK(hipStreamSynchronize(s));
         if (!flag) return ALABI_OK;
-        // timed out (workgroups not co-resident?): fall through to the launch-per-step kernels
+        // timed out (workgroups not co-resident?): fall through to the launch-per-step kernels, and skip the dataflow
+        // kernel for the next 256 solves of this process
+        stream_penalty.store(256, std::memory_order_relaxed);
         hipLaunchKernelGGL(residual_kernel, dim3((gp->Npad + 255) / 256), dim3(256), 0, s, gp->y, gp->N, gp->Npad, gp->mean, r);
     }
     for (int kb = 0; kb < nb; ++kb)

@@ -53,12 +53,16 @@ class _KernelView:
         return self._gp.ndim
 
     def get_parameter_names(self, include_frozen=False):
+        if not getattr(self._gp, "fit_amp", True):
+            extra = ["log_alpha"] if self._gp.kernel_name == "RationalQuadraticKernel" else []
+            return tuple(extra + [f"metric:log_M_{i}_{i}" for i in range(self._gp.ndim)])
         extra = ["k2:log_alpha"] if self._gp.kernel_name == "RationalQuadraticKernel" else []
         return tuple(["k1:log_constant"] + extra + [f"k2:metric:log_M_{i}_{i}" for i in range(self._gp.ndim)])
 
     def get_parameter_vector(self, include_frozen=False):
         extra = [self._gp.log_alpha] if self._gp.kernel_name == "RationalQuadraticKernel" else []
-        return np.concatenate([[self._gp.log_constant], extra, self._gp.log_M])
+        head = [self._gp.log_constant] if getattr(self._gp, "fit_amp", True) else []
+        return np.concatenate([head, extra, self._gp.log_M])
 
     def get_value(self, x1, x2=None, diag=False):
         gp = self._gp
@@ -103,7 +107,7 @@ class _SolverView:
 
 class HipGP:
     def __init__(self, ndim, mean=0.0, white_noise=-12.0, log_constant=0.0, log_M=None,
-                 fit_mean=True, fit_white_noise=True, kernel="ExpSquaredKernel", log_alpha=1.0):
+                 fit_mean=True, fit_white_noise=True, kernel="ExpSquaredKernel", log_alpha=1.0, fit_amp=True):
         if kernel not in _lib.KERNEL_CODES:
             raise ValueError(f"Kernel '{kernel}' is not a valid option. Valid options: {', '.join(_lib.KERNEL_CODES)}")
         self.kernel_name = kernel
@@ -119,6 +123,9 @@ class HipGP:
             raise ValueError("log_M must have ndim entries")
         self.fit_mean = bool(fit_mean)
         self.fit_white_noise = bool(fit_white_noise)
+        # fit_amp=False: the reference builds the bare kernel (no ``kernel *= var(y)``, gp_utils.py:230), so george's model
+        # has no constant factor and no log_constant parameter; the amplitude stays at exp(log_constant) here (0.0 = 1).
+        self.fit_amp = bool(fit_amp)
         self.kernel = _KernelView(self)
         self.solver = _SolverView(self)
         self._x = None          # numpy [N,d] (host copy: pickling, protocol)
@@ -189,10 +196,12 @@ class HipGP:
             names.append("mean:value")
         if self.fit_white_noise or include_frozen:
             names.append("white_noise:value")
-        names.append("kernel:k1:log_constant")
+        if getattr(self, "fit_amp", True):
+            names.append("kernel:k1:log_constant")
+        k2 = "kernel:k2" if getattr(self, "fit_amp", True) else "kernel"     # no product kernel without the constant factor
         if self.kernel_name == "RationalQuadraticKernel":
-            names.append("kernel:k2:log_alpha")
-        names += [f"kernel:k2:metric:log_M_{i}_{i}" for i in range(self.ndim)]
+            names.append(f"{k2}:log_alpha")
+        names += [f"{k2}:metric:log_M_{i}_{i}" for i in range(self.ndim)]
         return tuple(names)
 
     def get_parameter_vector(self, include_frozen=False):
@@ -201,7 +210,8 @@ class HipGP:
             v.append(self.mean_value)
         if self.fit_white_noise or include_frozen:
             v.append(self.white_noise_value)
-        v.append(self.log_constant)
+        if getattr(self, "fit_amp", True):
+            v.append(self.log_constant)
         if self.kernel_name == "RationalQuadraticKernel":
             v.append(self.log_alpha)
         v.extend(self.log_M.tolist())
@@ -222,7 +232,8 @@ class HipGP:
             self.mean_value = float(p[i]); i += 1
         if self.fit_white_noise or include_frozen:
             self.white_noise_value = float(p[i]); i += 1
-        self.log_constant = float(p[i]); i += 1
+        if getattr(self, "fit_amp", True):
+            self.log_constant = float(p[i]); i += 1
         if self.kernel_name == "RationalQuadraticKernel":
             self.log_alpha = float(p[i]); i += 1
         self.log_M = p[i:i + self.ndim].copy()
@@ -449,7 +460,8 @@ class HipGP:
             g.append(full[0])
         if self.fit_white_noise:
             g.append(full[1])
-        g.append(full[2])
+        if getattr(self, "fit_amp", True):
+            g.append(full[2])
         if self.kernel_name == "RationalQuadraticKernel":
             g.append(full[3])
         g.extend(full[4:4 + self.ndim])

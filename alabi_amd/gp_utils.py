@@ -55,7 +55,7 @@ def configure_gp(theta, y, kernel, fit_amp=True, fit_mean=True, fit_white_noise=
     log_const = np.log(np.var(y) / ndim) if fit_amp else kernel.get("log_constant", 0.0)
     gp = HipGP(ndim, mean=np.median(y), white_noise=white_noise, log_constant=log_const, log_M=kernel["log_M"],
                fit_mean=fit_mean, fit_white_noise=fit_white_noise, kernel=kernel.get("name", "ExpSquaredKernel"),
-               log_alpha=kernel.get("log_alpha", 1.0))
+               log_alpha=kernel.get("log_alpha", 1.0), fit_amp=fit_amp)
     if hyperparameters is not None:
         if np.any(~np.isfinite(hyperparameters)):
             raise ValueError("All hyperparameter values must be finite!")

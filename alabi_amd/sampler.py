@@ -38,12 +38,21 @@ class State:
 
 class EnsembleSampler:
     def __init__(self, nwalkers, ndim, gp, y, bounds, seed=None, a=2.0, pool=None, live_dangerously=False,
-                 n_ensembles=1, logp_affine=(1.0, 0.0), normal_prior=None, **unused):
+                 n_ensembles=1, logp_affine=(1.0, 0.0), normal_prior=None, logp_map=None, prior_fn=None, like_fn=None,
+                 gate_box=True, **unused):
         """``n_ensembles`` > 1 runs that many INDEPENDENT ensembles of ``nwalkers`` walkers in the same kernel
         launches (rows [e*nwalkers, (e+1)*nwalkers) of every array belong to ensemble e).
         ``logp_affine=(scale, shift)``: log-probability = scale * GP mean + shift inside the box (an affine y scaler).
         ``normal_prior=(mean[d], std[d])``: independent normal priors on top of the box (NaN / non-positive std = none on
-        that coordinate), the reference's ``lnprior_normal``."""
+        that coordinate), the reference's ``lnprior_normal``.
+        ``logp_map``: None, "nlog" or "log" -- the inverse of the reference's non-affine y scalers (-10^x, 10^x,
+        alabi/utility.py:62-71) applied to the (affinely mapped) GP mean inside the kernels.
+        ``prior_fn`` / ``like_fn``: arbitrary HOST callables on a batch of points in the sampler's coordinates
+        ([n,d] -> [n]); the reference's lnprob = like_fn + prior_fn with any Python callable (alabi/core.py:2073-2100).
+        With either one set, every half step is split into a propose launch, the host call and an accept launch
+        (alabi_ens_propose / alabi_ens_accept): the ensemble, the draws and the accept test stay on the device.  With
+        ``like_fn=None`` the surrogate part is evaluated by the propose kernel; ``gate_box`` says whether that value is
+        -inf outside ``bounds`` (True when the prior is the box itself, False when ``prior_fn`` is the whole prior)."""
         if not isinstance(gp, HipGP):
             raise TypeError("EnsembleSampler needs the HipGP surrogate (the log-probability is fused into the kernel)")
         self.nwalkers = int(nwalkers)
@@ -65,10 +74,21 @@ class EnsembleSampler:
             m = np.ascontiguousarray(np.asarray(normal_prior[0], dtype=np.float64).reshape(self.ndim))
             sd = np.ascontiguousarray(np.asarray(normal_prior[1], dtype=np.float64).reshape(self.ndim))
             self.normal_prior = (m, sd)
+        if logp_map not in (None, "nlog", "log"):
+            raise ValueError("logp_map must be None, 'nlog' or 'log'")
+        self.logp_map = logp_map
+        self.prior_fn_host = prior_fn
+        self.like_fn_host = like_fn
+        self.generic = prior_fn is not None or like_fn is not None
+        self.gate_box = bool(gate_box)
+        if self.generic and self.n_ensembles != 1:
+            raise ValueError("host callables need n_ensembles == 1")
         if seed is None:
             seed = int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).view(np.uint64)[0])
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.iteration = 0
+        self._rng_step = 0      # global step index of the counter-based draws: never rewound (reset() keeps it, as emcee's
+                                # reset() keeps the RandomState), so a burn-in / reset / production run uses fresh draws
         self._coords = None
         self._logp = None
         self._chains = []
@@ -82,8 +102,13 @@ class EnsembleSampler:
 
     # ------------------------------------------------------------------ handle lifetime
     def _ensure_ens(self):
-        self.gp.predict_device(self._y, torch.zeros((1, self.ndim), dtype=torch.float64, device=_dev()))  # alpha ready
-        h = self.gp.handle
+        if self.like_fn_host is None:
+            self.gp.predict_device(self._y, torch.zeros((1, self.ndim), dtype=torch.float64, device=_dev()))  # alpha ready
+            h = self.gp.handle
+        else:                    # the surrogate is not evaluated on the device: the GP only owns the ensemble handle
+            if self.gp._handle is None:
+                self.gp._ensure_handle(64)
+            h = self.gp._handle
         if self._ens is not None and self._ens_gp_handle is not None and self._ens_gp_handle.value == h.value:
             return
         self._release()
@@ -98,6 +123,8 @@ class EnsembleSampler:
             _lib.check(_lib.lib().alabi_ens_set_normal_prior(e, _lib.host_doubles(self.normal_prior[0]),
                                                              _lib.host_doubles(self.normal_prior[1])),
                        "alabi_ens_set_normal_prior")
+        if self.logp_map is not None:
+            _lib.check(_lib.lib().alabi_ens_set_logp_map(e, {"nlog": 1, "log": 2}[self.logp_map]), "alabi_ens_set_logp_map")
         self._ens = e
         self._ens_gp_handle = C.c_void_p(h.value)
 
@@ -119,6 +146,8 @@ class EnsembleSampler:
         st["_ens"] = None
         st["_ens_gp_handle"] = None
         st["_stream"] = None
+        st["prior_fn_host"] = None      # host callables (often closures) are not part of the saved state
+        st["like_fn_host"] = None
         for k in ("_coords", "_logp", "_naccept"):
             st[k] = None if st[k] is None else st[k].cpu()
         st["_chains"] = [c.cpu() for c in self._chains]
@@ -141,8 +170,71 @@ class EnsembleSampler:
         if c.shape != (self.total_walkers, self.ndim):
             raise ValueError("coords must have shape (nwalkers * n_ensembles, ndim)")
         lp = torch.empty(self.total_walkers, dtype=torch.float64, device=c.device)
+        if self.generic:
+            return self._host_log_prob(c, self.surrogate(c) if self.like_fn_host is None else None)
         _lib.check(_lib.lib().alabi_ens_lnprob(self._ens, _lib.ptr(c), _lib.ptr(lp), _lib.current_stream()), "alabi_ens_lnprob")
         return lp
+
+    def surrogate(self, points):
+        """y_scaler^-1(GP mean) at arbitrary points [M,d] in the sampler's coordinates: no box gate, no prior (device tensor)."""
+        self._ensure_ens()
+        c = _to_dev(points, 2)
+        out = torch.empty(c.shape[0], dtype=torch.float64, device=c.device)
+        _lib.check(_lib.lib().alabi_ens_surrogate(self._ens, _lib.ptr(c), int(c.shape[0]), _lib.ptr(out), _lib.current_stream()),
+                   "alabi_ens_surrogate")
+        return out
+
+    def _host_log_prob(self, q_dev, like_dev):
+        """like (device values, or like_fn on the host) + prior_fn on the host for a batch of points; device tensor out.
+        NaN raises as emcee does ("Probability function returned NaN")."""
+        qh = q_dev.cpu().numpy()
+        if like_dev is not None:
+            lp = like_dev.cpu().numpy().copy()
+        elif self.gate_box:                          # a host likelihood under the box prior: only evaluated inside the box
+            inside = np.all((qh > self.bounds[:, 0]) & (qh < self.bounds[:, 1]), axis=1)
+            lp = np.full(qh.shape[0], -np.inf)
+            if inside.any():
+                lp[inside] = np.asarray(self.like_fn_host(qh[inside]), dtype=np.float64).reshape(-1)
+        else:
+            lp = np.asarray(self.like_fn_host(qh), dtype=np.float64).reshape(-1).copy()
+        if self.prior_fn_host is not None:
+            lp = lp + np.asarray(self.prior_fn_host(qh), dtype=np.float64).reshape(-1)
+        if lp.shape != (qh.shape[0],):
+            raise ValueError("like_fn / prior_fn must return one value per point")
+        if np.any(np.isnan(lp)):
+            raise ValueError("Probability function returned NaN")
+        return torch.as_tensor(lp, device=q_dev.device)
+
+    def _run_generic(self, nsteps, thin_by, chain, chain_lp):
+        """Half steps split around the host callables (alabi_ens_propose -> host -> alabi_ens_accept)."""
+        lib, W, d = _lib.lib(), self.nwalkers, self.ndim
+        n0 = (W + 1) // 2
+        dev = self._coords.device
+        stream = _lib.current_stream()
+        want_like = self.like_fn_host is None
+        done = 0
+        while done < nsteps:
+            n = min(256, nsteps - done)
+            _lib.check(lib.alabi_ens_draw(self._ens, self._rng_step + done, n, self.a, stream), "alabi_ens_draw")
+            for t in range(n):
+                for split in (0, 1):
+                    nS = n0 if split == 0 else W - n0
+                    if nS == 0:
+                        continue
+                    q = torch.empty((nS, d), dtype=torch.float64, device=dev)
+                    like = torch.empty(nS, dtype=torch.float64, device=dev) if want_like else None
+                    _lib.check(lib.alabi_ens_propose(self._ens, _lib.ptr(self._coords), t, split, int(self.gate_box),
+                                                     _lib.ptr(q), _lib.ptr(like), stream), "alabi_ens_propose")
+                    lp_new = self._host_log_prob(q, like)
+                    _lib.check(lib.alabi_ens_accept(self._ens, _lib.ptr(self._coords), _lib.ptr(self._logp), t, split,
+                                                    _lib.ptr(q), _lib.ptr(lp_new), _lib.ptr(self._naccept), stream),
+                               "alabi_ens_accept")
+                k = done + t + 1
+                if chain is not None and k % thin_by == 0:
+                    chain[k // thin_by - 1].copy_(self._coords)
+                    chain_lp[k // thin_by - 1].copy_(self._logp)
+            done += n
+        torch.cuda.current_stream().synchronize()
 
     def run_mcmc(self, initial_state, nsteps, thin_by=1, progress=False, store=True, skip_initial_state_check=False, **kw):
         nsteps = int(nsteps)
@@ -177,12 +269,23 @@ class EnsembleSampler:
         chain = torch.empty((nstore, self.total_walkers, self.ndim), dtype=torch.float64, device=dev) if nstore else None
         chain_lp = torch.empty((nstore, self.total_walkers), dtype=torch.float64, device=dev) if nstore else None
         t0 = time.perf_counter()
-        self._stream.wait_stream(torch.cuda.current_stream())
+        if self.generic:
+            self._run_generic(nsteps, thin_by, chain, chain_lp)
+            self.last_path = "host-callback"
+            self.last_run_seconds = time.perf_counter() - t0
+            self.iteration += nsteps
+            self._rng_step += nsteps
+            if nstore:
+                self._chains.append(chain); self._chain_lps.append(chain_lp); self._thins.append(thin_by)
+            return State(self._coords.cpu().numpy(), self._logp.cpu().numpy())
+        # the backup copies are taken on the current stream BEFORE the run stream is made to wait for it: the run's
+        # kernels (which update coords / logp in place) are then ordered after them
         backup = (self._coords.clone(), self._logp.clone(), self._naccept.clone())
+        self._stream.wait_stream(torch.cuda.current_stream())
 
         def _run():
             with torch.cuda.stream(self._stream):
-                return _lib.lib().alabi_ens_run(self._ens, _lib.ptr(self._coords), _lib.ptr(self._logp), self.iteration,
+                return _lib.lib().alabi_ens_run(self._ens, _lib.ptr(self._coords), _lib.ptr(self._logp), self._rng_step,
                                                 nsteps, thin_by, self.a, _lib.ptr(chain), _lib.ptr(chain_lp),
                                                 _lib.ptr(self._naccept), C.c_void_p(self._stream.cuda_stream))
 
@@ -203,6 +306,7 @@ class EnsembleSampler:
         torch.cuda.current_stream().wait_stream(self._stream)
         self.last_run_seconds = time.perf_counter() - t0
         self.iteration += nsteps
+        self._rng_step += nsteps
         if nstore:
             self._chains.append(chain)
             self._chain_lps.append(chain_lp)
@@ -210,6 +314,7 @@ class EnsembleSampler:
         return State(self._coords.cpu().numpy(), self._logp.cpu().numpy())
 
     def reset(self):
+        """emcee's reset(): forget the chain and the acceptance counts.  The draw counter is NOT rewound."""
         self._chains, self._chain_lps, self._thins = [], [], []
         self._naccept.zero_()
         self.iteration = 0

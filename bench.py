@@ -49,7 +49,7 @@ def _cpu_lnprob(theta):
     return float((k @ _CPU["alpha"])[0] + h["mean"]) + lp
 
 
-def cpu_baseline_vectorized(cfg, budget_s=5.0):
+def cpu_baseline_vectorized(cfg, budget_s=5.0, keep_chain=None):
     """A stronger CPU statement than the reference's own call shape: the whole half-ensemble's proposals evaluated in one
     NumPy call (what emcee's vectorize=True would allow).  Reported beside the reference-shaped baselines so the GPU/CPU
     ratio is not read off the per-walker Python-call overhead alone."""
@@ -83,6 +83,8 @@ def cpu_baseline_vectorized(cfg, budget_s=5.0):
         partner = np.where(lab == 0, rs.randint(W - n0, size=W), rs.randint(max(n0, 1), size=W))
         coords, logp, _ = so.stretch_step_arrays(coords, logp, order, n0, rs.rand(W), partner, rs.rand(W), lnprob_batch)
         nsteps += 1
+        if keep_chain is not None:
+            keep_chain.append(coords.copy())
     dt = time.perf_counter() - t0
     return {"value": cfg["W"] * nsteps / dt, "unit": "samples/s", "cores": "numpy default threads", "kind": "port",
             "sample": f"{nsteps} stretch-move steps x {cfg['W']} walkers ({dt:.1f} s), half-ensemble proposals evaluated "
@@ -139,6 +141,43 @@ def cpu_baseline(cfg, budget_s=10.0, cores=1):
                       ", single-point mean-only predict with cached factorisation"}
 
 
+def parity_gate(cfg, gp, y_dev, cpu_chain, args):
+    """SURVEY.md section 8(d)'s correctness gate, outside the timed region: GPU predict against the CPU oracle on 256
+    points, and the two-sample KS distance per marginal between a fresh GPU chain and the CPU (vectorised oracle) chain of
+    this same run.  The CPU chain is short (12 s of host time), so its effective sample size -- not the GPU -- sets the KS
+    noise floor: tests/test_gpu_configs.py::test_C3_ks_distance_gpu_vs_cpu_chain holds the < 0.01 assertion with a long one."""
+    import torch
+    from scipy.stats import ks_2samp
+    from alabi_amd import EnsembleSampler
+    from alabi_amd.mcmc_utils import integrated_time
+    from oracle.gp_oracle import OracleGP
+    h, d, W = cfg["hyper"], cfg["d"], cfg["W"]
+    o = OracleGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(cfg["X"])
+    b = cfg["bounds"]
+    Xs = np.random.RandomState(11).uniform(b[:, 0], b[:, 1], (256, d))
+    mu, var = gp.predict_device(y_dev, torch.as_tensor(Xs, device="cuda"), return_var=True)
+    mu_o, var_o = o.predict(cfg["y"], Xs, return_var=True)
+    gate = {"points": 256,
+            "max_dmu_rel": float(np.max(np.abs(mu.cpu().numpy() - mu_o) / (np.abs(mu_o) + 1.0))), "tol_dmu_rel": 1e-8,
+            "max_dvar_over_amp": float(np.max(np.abs(var.cpu().numpy() - var_o)) / np.exp(h["log_amp"])), "tol_dvar_over_amp": 1e-6}
+    gate["predict_ok"] = bool(gate["max_dmu_rel"] <= 1e-8 and gate["max_dvar_over_amp"] <= 1e-6)
+    if cpu_chain:
+        burn = min(1500, len(cpu_chain) // 4)
+        cpu = np.asarray(cpu_chain[burn:])                                   # [steps, W, d]
+        s = EnsembleSampler(W, d, gp, cfg["y"], b, seed=4711)
+        s.run_mcmc(cfg["p0"], 2000, store=False)
+        s.run_mcmc(None, 100_000, thin_by=4)
+        gpu = s.get_chain(flat=True)
+        tau = float(np.max(integrated_time(torch.as_tensor(cpu, device="cuda"), tol=0))) if cpu.shape[0] > 50 else float("nan")
+        ks = [float(ks_2samp(gpu[:, k], cpu[:, :, k].ravel()).statistic) for k in range(d)]
+        n_eff = cpu.shape[0] * W / tau if tau == tau and tau > 0 else float("nan")
+        gate.update({"ks_max": max(ks), "ks_per_marginal": ks, "ks_target": 0.01, "ks_gpu_samples": int(gpu.shape[0]),
+                     "ks_cpu_samples": int(cpu.shape[0] * W), "ks_cpu_autocorr_steps": tau, "ks_cpu_n_eff": n_eff,
+                     "ks_noise_floor_1sigma": float(0.6 / np.sqrt(n_eff)) if n_eff == n_eff else None,
+                     "ks_ok": bool(max(ks) < 0.01)})
+    return gate
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,6 +198,20 @@ def main():
                          "opt-in so that an untested collective path can never cost the headline line")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks here, BEFORE anything in this process touches the GPU (no
+        # torch import yet), as a child torch.distributed.run (one process per GPU, RCCL), and pass its exit code on
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import torch
     import torch.distributed as dist
     from alabi_amd import EnsembleSampler, HipGP
@@ -171,10 +224,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     # CPU baselines first: the multi-core one forks a pool, which must happen before the GPU is initialised
     cpu_base = cpu_base_all = cpu_base_vec = cpu_pred = None
+    cpu_chain = None
     if world == 1 and not args.no_cpu_baseline:
         cfg0 = make_config(args.config, N=args.ntrain, W=args.walkers)
         cpu_base = cpu_baseline(cfg0, budget_s=10.0, cores=1)
-        cpu_base_vec = cpu_baseline_vectorized(cfg0, budget_s=5.0)
+        cpu_chain = []
+        cpu_base_vec = cpu_baseline_vectorized(cfg0, budget_s=12.0, keep_chain=cpu_chain)
         cpu_pred = cpu_predict_baseline(cfg0)
         ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         ncores = max(1, min(ncores, 64))
@@ -333,7 +388,8 @@ def main():
                     traffic *= min(args.mcmc_steps, 1024) / float(pmc.get("steps_per_launch", 1024))
             except Exception:  # noqa: BLE001
                 traffic = None
-        out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        out["roofline"] = {"bound": "fp64-valu", "regime": "latency (dependent half-step chain, no MFMA in this kernel)",
+                           "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                            "kernel": kernel_name, "path": path, "us_per_launch_incl_boundary": us_per_launch,
                            "us_per_half_step": 1e3 * ev_ms / (args.steps * 2 * args.mcmc_steps),
@@ -368,11 +424,17 @@ def main():
             pv_tf = pv_flops * extras["predict_meanvar_pts_per_s_M65536"] / 65536.0 / 1e12
             extras["roofline_predict_var"] = {"bound": "mfma", "achieved": pv_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                               "frac": pv_tf / FP64_PEAK_TFLOPS, "kernel": "predict_kstar_tile_kernel + predict_var_w2_kernel", "sustained_mfma_peak_measured": {"one_wave_per_simd": 59.1, "two_waves_per_simd": 68.0}}
+            pm_tf = extras["predict_mean_pts_per_s_M1e6"] * N * (2 * d + 3) / 1e12
+            extras["roofline_predict_mean"] = {"bound": "fp64-valu", "achieved": pm_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": pm_tf / FP64_PEAK_TFLOPS, "kernel": "predict_mean_tile_kernel",
+                                               "flops_per_point": N * (2 * d + 3)}
             ch_tf = extras["cholesky_gflops"] / 1e3
             extras["roofline_cholesky"] = {"bound": "mfma", "achieved": ch_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                            "frac": ch_tf / FP64_PEAK_TFLOPS, "kernel": "trsm_panel + syrk_update with fused diagonal potrf (N^3/3 flops)",
                                            "note": "N=2000 is latency-bound on the panel critical path; see DESIGN.md for N=10000"}
             out["extras"] = extras
+        if world == 1 and not args.no_cpu_baseline:
+            out["parity_gate"] = parity_gate(cfg, gp, y_dev, cpu_chain, args)
         if shard_info is not None:
             out["sharded_ensemble"] = shard_info
         if cpu_base is not None:

@@ -162,6 +162,11 @@ int alabi_ens_set_normal_prior(alabi_ens* ens, const double* mean, const double*
  * affine-invariant).  scale > 0.  Affects alabi_ens_lnprob / run / half_step from the next call on. */
 int alabi_ens_set_logp_affine(alabi_ens* ens, double scale, double shift);
 
+/* Non-affine y scalers the reference ships (alabi/utility.py:62-71; un-scaling per prediction at alabi/core.py:1483-1502):
+ * the log-probability becomes map(scale * GP mean + shift) with kind 0 identity (default), 1 nlog_scaler's inverse -10^x,
+ * 2 log_scaler's inverse 10^x.  Applied inside every ensemble kernel, once per proposal. */
+int alabi_ens_set_logp_map(alabi_ens* ens, int kind);
+
 /* Enable / disable the persistent dataflow kernel for alabi_ens_run on this handle (default: enabled when the
  * ensemble fits one workgroup per CU).  Returns ALABI_BAD_ARGUMENT when enabling is impossible. */
 int alabi_ens_set_stream(alabi_ens* ens, int enabled);
@@ -170,6 +175,10 @@ int alabi_ens_last_path(alabi_ens* ens, int* path /* host */);
 
 /* log-probability of every walker (surrogate mean + box prior): coords [E*W,d] -> logp [E*W]. */
 int alabi_ens_lnprob(alabi_ens* ens, const double* coords, double* logp, void* stream);
+
+/* The surrogate part alone, y_scaler^-1(GP mean), at M arbitrary points [M,d] in the sampler's coordinates -- no box
+ * gate, no prior (alabi/core.py:1446-1508 surrogate_log_likelihood as lnprob's like_fn, :2073-2100). */
+int alabi_ens_surrogate(alabi_ens* ens, const double* points, int M, double* like, void* stream);
 
 /* Run nsteps full stretch-move steps on one GPU.  coords [E*W,d] and logp [E*W] are updated in
  * place; chain [nsteps/thin_by, E*W, d] and chain_logp [nsteps/thin_by, E*W] receive every
@@ -187,6 +196,18 @@ int alabi_ens_run(alabi_ens* ens, double* coords, double* logp, long long step0,
 int alabi_ens_draw(alabi_ens* ens, long long step0, int nsteps, double a, void* stream);
 int alabi_ens_half_step(alabi_ens* ens, double* coords, double* logp, int t, int split,
                         int part_begin, int part_end, long long* n_accept, void* stream);
+/* Generic log-probability (n_ensembles == 1): the reference's lnprob = like_fn(theta) + prior_fn(theta) accepts ANY
+ * Python callables (alabi/core.py:2073-2100, :2253-2280; docstring example :2236-2239).  A half step of drawn local step
+ * `t` is split around the host call: alabi_ens_propose writes the proposals of that half in LIST order to q [nS,d]
+ * (nS = ceil(W/2) for split 0, floor(W/2) for split 1) and, if `like` is not NULL, the surrogate part
+ * y_scaler^-1(GP mean) at each proposal (-inf outside the box when gate_box != 0); the caller forms
+ * lp_new [nS] = like (or its own like_fn) + prior_fn(q); alabi_ens_accept applies emcee's accept test
+ * (d-1) ln z + lp_new - logp > ln u' with the step's draws and updates coords / logp / n_accept in place.
+ * A NaN lp_new rejects. */
+int alabi_ens_propose(alabi_ens* ens, const double* coords, int t, int split, int gate_box,
+                      double* q, double* like, void* stream);
+int alabi_ens_accept(alabi_ens* ens, double* coords, double* logp, int t, int split,
+                     const double* q, const double* lp_new, long long* n_accept, void* stream);
 /* copy of the walker lists of drawn local step t: order_out[W] int32 (device), n0 (host). */
 int alabi_ens_step_lists(alabi_ens* ens, int t, int* order_out, int* n0, void* stream);
 
