@@ -476,6 +476,7 @@ int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* 
             if (err == hipSuccess) err = hipMalloc(&e->hist, hist_words * sizeof(unsigned long long));
             if (err == hipSuccess) err = hipMalloc(&e->err, sizeof(int));
             e->stream_ok = (err == hipSuccess) ? 1 : 0;
+            e->spec_ok = (e->stream_ok && (long long)W * n_ensembles <= n_cu) ? 1 : 0;
         }
     }
     if (err != hipSuccess) {

@@ -138,8 +138,9 @@ struct alabi_ens {
     unsigned long long* hist = nullptr;  // [(chunk_cap+1)][E*W][d+1] version history of every walker
     int* err = nullptr;                  // [1] spin time-out flag
     int stream_grid = 0;                 // workgroups per ensemble of the persistent kernel
-    int last_path = 0;                   // 1 if the last run used the persistent kernel
+    int last_path = 0;                   // 1 persistent kernel, 2 its speculative variant, 0 one launch per half step
     int stream_ok = 0;                   // eligible: training set fits the lanes' registers, one workgroup per CU
+    int spec_ok = 0;                     // W * E workgroups fit one per CU: the speculative persistent kernel (ens_spec_kernel)
 };
 
 namespace alabi {

@@ -31,6 +31,7 @@
 // The per-step work at the headline size (W=256, N=2000, d=10) is 2 x 128 workgroups x
 // 2000 kernel evaluations: latency bound, not HBM bound (X and alpha, 176 KB, stay in L2).
 #include <cstdlib>
+#include <vector>
 #include "gp_device.hpp"
 
 namespace alabi {
@@ -531,6 +532,7 @@ struct StreamArgs {
     unsigned long long* n_accept;
     const long long* run_state;
     int K, W, n0, d, Npad, thin_by, spin_limit, has_prior;
+    long long* dbg;              // nullable: per-workgroup counters of ens_spec_kernel (ALABI_SPEC_DBG=1)
     double amp, mean, prior_const;
     KernelFn kf;
 };
@@ -792,6 +794,280 @@ extern "C" int alabi_debug_stream_prof(long long* out) {
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------------
+// Speculative variant of the persistent kernel, for W * E <= #CUs (the headline: ONE 256-walker ensemble on 256 CUs).
+// ens_stream_kernel leaves half the chip idle there (128 proposals per half step) and every half step costs
+//   hand-off (0.55 us) + proposal (0.15) + kernel sum (0.9) + accept / store (0.2)
+// in sequence.  Here every list position of BOTH halves has its own workgroup, so a workgroup owns one proposal per
+// STEP and is idle during the other half step.  It uses that time to evaluate its next proposal EARLY from stand-in
+// inputs: a row that has not been published yet is replaced by the walker's previous version, which is what the row
+// will turn out to be whenever that walker's pending update is rejected (59 % at the headline configuration; the
+// acceptance flag travels in the row).  When the real rows arrive and none of them changed, the kernel sum is already
+// there and only the accept test and the row store remain on the dependency chain; otherwise the proposal is formed
+// again from the real rows and evaluated as in ens_stream_kernel.  The result never depends on the guess: the value
+// that enters the accept test is always the sum evaluated at the proposal built from the real rows (same lane -> point
+// map and summation order as ens_half_kernel: chains stay bit-identical to the other two paths).
+// Rounds: an item (one proposal) consists of one or more rounds {barrier A: proposal in LDS; kernel sum; barrier B};
+// ctl_s[par][0] written by wave 0 before barrier B tells the other waves whether another round of the same item follows.
+template <int D, int PPT, int TMAX, bool GENERIC>
+__global__ void __launch_bounds__(TMAX)
+ens_spec_kernel(StreamArgs p) {
+    __shared__ __attribute__((aligned(16))) double scratch[2][16];
+    __shared__ unsigned long long rec_s[4][4];
+    __shared__ __attribute__((aligned(16))) double qs_s[2][ALABI_MAX_DIM];
+    __shared__ double consts_s[5][ALABI_MAX_DIM];
+    __shared__ int ctl_s[2][2];                                      // [round parity][0] 1 = item finished, no kernel sum; [0][1] abort
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int TC = blockDim.x - 128, nwc = TC >> 6;
+    const bool comm = wv == 0, service = wv == nwc + 1, compute = !comm && !service;
+    const int g = blockIdx.x, e = blockIdx.y, E = gridDim.y;
+    const int WT = p.W * E, row = p.d + 2;
+    const int split = g >= p.n0 ? 1 : 0;                  // this workgroup's list position g (set 0 then set 1), every step
+    const int half = p.Npad >> 1, ct = tid - 64;
+    f64x2 xa[PPT][D], aa[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int idx = ct + j * TC;
+        const bool v = compute && idx < half;
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            xa[j][k] = v ? reinterpret_cast<const f64x2*>(p.Xt + (size_t)k * p.Npad)[idx] : f64x2{0.0, 0.0};
+        aa[j] = v ? reinterpret_cast<const f64x2*>(p.alpha)[idx] : f64x2{0.0, 0.0};
+    }
+    if (tid < ALABI_MAX_DIM) {
+        consts_s[0][tid] = (tid < p.d) ? p.consts[tid] : 0.0;
+        consts_s[1][tid] = (tid < p.d) ? p.consts[ALABI_MAX_DIM + tid] : 0.0;
+        consts_s[2][tid] = (tid < p.d) ? p.consts[2 * ALABI_MAX_DIM + tid] : 0.0;
+        consts_s[3][tid] = (tid < p.d) ? p.consts[3 * ALABI_MAX_DIM + tid] : 0.0;
+        consts_s[4][tid] = (tid < p.d) ? p.consts[4 * ALABI_MAX_DIM + tid] : 0.0;
+    }
+    if (tid < 32) scratch[tid >> 4][tid & 15] = 0.0;
+    if (tid < 4) ctl_s[tid >> 1][tid & 1] = 0;
+    // proposal records of steps 0, 1 into the ring, step 2 in flight (lane l < 4 of the last wave loads word l)
+    const unsigned long long* packed = p.rec.packed;
+    auto record_load = [&](int t) -> unsigned long long {
+        if (t >= p.K || lane >= 4) return 0ull;
+        const size_t rp = ((size_t)t * E + e) * p.W + g;
+        return packed[4 * rp + lane];
+    };
+    unsigned long long pend = 0;
+    if (service) {
+        for (int i = 0; i < 2; ++i) {
+            const unsigned long long v = record_load(i);
+            if (lane < 4) rec_s[i][lane] = v;
+        }
+        pend = record_load(2);
+    }
+    __syncthreads();
+    int rnd = 0;                                          // rounds so far: parity selects the LDS buffers
+    if (!comm) {
+        // ---- compute and record waves: serve rounds until the kernel ends
+        for (int t = 0; t < p.K; ++t) {
+            bool fetched = false;
+            for (;;) {
+                const int par = rnd & 1;
+                __syncthreads();                           // barrier A: wave 0 has published a proposal, or closed the item
+                ++rnd;
+                if (ctl_s[0][1]) return;
+                if (ctl_s[par][0]) break;                  // item finished
+                double qraw[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) qraw[k] = qs_s[par][k];
+                const int cin = __builtin_amdgcn_readfirstlane(__double2hiint(qs_s[par][63])) != 0;
+                if (compute && cin) {
+                    double q[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k)
+                        q[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(qraw[k])),
+                                                __builtin_amdgcn_readfirstlane(__double2loint(qraw[k])));
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < PPT; ++j) {
+                        double r2a = 0.0, r2b = 0.0;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            const double da = xa[j][k].x - q[k], db = xa[j][k].y - q[k];
+                            r2a = fma(da, da, r2a);
+                            r2b = fma(db, db, r2b);
+                        }
+                        acc = (j == 0) ? aa[j].x * radial<GENERIC>(r2a, p.kf) : fma(aa[j].x, radial<GENERIC>(r2a, p.kf), acc);
+                        acc = fma(aa[j].y, radial<GENERIC>(r2b, p.kf), acc);
+                        if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const double wsum = wave_sum_dpp(acc);
+                    if (lane == 63) scratch[par][wv - 1] = wsum;
+                }
+                if (service && !fetched) {                 // once per item: ring slot t+2, issue t+3
+                    if (lane < 4) rec_s[(t + 2) & 3][lane] = pend;
+                    pend = record_load(t + 3);
+                    fetched = true;
+                }
+                __syncthreads();                           // barrier B: the partial sums are in LDS
+            }
+        }
+        return;
+    }
+    // ---- wave 0: the dependency chain.  Lanes 0..31 watch the walker's own row, lanes 32..63 the partner's row
+    // (word hl of the row in lane hl: coordinates, logp, acceptance flag), so ONE load instruction looks at both.
+    const int hl = lane & 31, grp = lane >> 5;
+    const bool need = hl <= p.d + 1;
+    const int wl = need ? hl : 0;                          // spare lanes re-read word 0 (keeps every lane's address valid)
+    const double il_r = consts_s[0][lane], lo_r = consts_s[1][lane], hi_r = consts_s[2][lane];
+    for (int t = 0; t < p.K; ++t) {
+        const unsigned long long* rs = rec_s[t & 3];
+        const unsigned long long ids = rs[0];
+        const int w = (int)(unsigned)(ids & 0xffffffffull), cw = (int)(unsigned)(ids >> 32);
+        const double zz = __longlong_as_double((long long)rs[1]);
+        const double lnfac = __longlong_as_double((long long)rs[2]), lnu = __longlong_as_double((long long)rs[3]);
+        // own row: version t; partner row: version t (+1 when its half went first)
+        const unsigned long long* pa = p.hist + ((size_t)(t + (grp ? split : 0)) * WT + (grp ? cw : w)) * row + wl;
+        const bool has_prev = grp ? (t + split > 0) : (t > 0);             // is there a previous version to stand in?
+        const unsigned long long* pb = has_prev ? pa - (size_t)WT * row : pa;
+        unsigned long long real = ALABI_HIST_EMPTY, prev = ALABI_HIST_EMPTY;
+        bool own_real = false, par_real = false;
+        bool have_sum = false, used_own_real = false, used_par_real = false;
+        int sum_par = 0, all_in = 0, spins = 0;
+        double qv = 0.0;
+        int n_rounds = 0, n_spec_rounds = 0, last_spec = 0;
+        // one look at the real rows: merge what has arrived (rows are immutable once written)
+#ifdef ALABI_SPEC_PROF
+        long long t_det_own = 0, t_det_par = 0, t_round = 0;
+        const long long t_item0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        auto merge = [&](unsigned long long v) {
+            if (real == ALABI_HIST_EMPTY) real = v;
+            const unsigned long long miss = __ballot(need && real == ALABI_HIST_EMPTY);
+#ifdef ALABI_SPEC_PROF
+            const bool o_ = own_real, p_ = par_real;
+#endif
+            own_real = (miss & 0xffffffffull) == 0ull;
+            par_real = (miss >> 32) == 0ull;
+#ifdef ALABI_SPEC_PROF
+            if (own_real && !o_) t_det_own = __builtin_amdgcn_s_memrealtime();
+            if (par_real && !p_) t_det_par = __builtin_amdgcn_s_memrealtime();
+#endif
+        };
+        merge(ld_sc1(pa));
+        for (;;) {
+            if (have_sum) {
+                // a guess is confirmed by "not accepted" in the real row (then the row IS the stand-in), refuted otherwise
+                if (!used_own_real && own_real) {
+                    if (__builtin_amdgcn_readlane((int)(unsigned)real, p.d + 1) == 0) used_own_real = true; else have_sum = false;
+                }
+                if (have_sum && !used_par_real && par_real) {
+                    if (__builtin_amdgcn_readlane((int)(unsigned)real, 32 + p.d + 1) == 0) used_par_real = true; else have_sum = false;
+                }
+                if (have_sum && used_own_real && used_par_real) break;      // the sum belongs to the real proposal: finish
+            }
+            bool go = false;
+            if (!have_sum) {
+                const bool grp_real = grp ? par_real : own_real;
+                if (!grp_real && has_prev && prev == ALABI_HIST_EMPTY) prev = ld_sc1(pb);
+                const unsigned long long miss = __ballot(need && !grp_real && (!has_prev || prev == ALABI_HIST_EMPTY));
+                go = miss == 0ull;
+            }
+            if (!go) {
+                // nothing to compute: watch the missing rows with two loads in flight (a look every half round trip)
+                // (relaxed agent-scope loads: the compiler keeps both in flight and waits with vmcnt(1), checked in the ISA)
+#ifdef ALABI_SPEC_PIPELINED_POLL
+                unsigned long long r1 = ld_sc1(pa), r2;
+                for (;;) {
+                    r2 = ld_sc1(pa);
+                    const bool o0 = own_real, p0 = par_real;
+                    merge(r1);
+                    if (own_real != o0 || par_real != p0) break;
+                    r1 = ld_sc1(pa);
+                    merge(r2);
+                    if (own_real != o0 || par_real != p0) break;
+                    if (!have_sum) break;                  // waiting for a stand-in: back to the outer loop to re-read it
+                    if ((spins += 2) > p.spin_limit ||
+                        ((spins & 62) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        spins = p.spin_limit;              // leave: the check below aborts
+                        break;
+                    }
+                }
+#else
+                merge(ld_sc1(pa));
+#endif
+                if ((spins += 1) > p.spin_limit ||
+                    ((spins & 63) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    if (lane == 0) { ctl_s[0][1] = 1; __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    __syncthreads();                       // releases the other waves at barrier A: they see the abort word
+                    return;
+                }
+                continue;
+            }
+            // a round: proposal from the best rows known, kernel sum by the compute waves
+            const int par = rnd & 1;
+            used_own_real = own_real; used_par_real = par_real;
+            ++n_rounds; last_spec = !(own_real && par_real); n_spec_rounds += last_spec;
+            const unsigned long long best = (grp ? par_real : own_real) ? real : prev;
+            const double sv = __longlong_as_double((long long)best);
+            const double cv = __shfl(sv, lane + 32, 64);   // lane k < 32: word k of the partner's row
+            int inb = 1;
+            double qs = 0.0;
+            if (lane < p.d) {
+                qv = cv - (cv - sv) * zz;
+                inb = (qv > lo_r) && (qv < hi_r);
+                qs = qv * il_r;
+            }
+            all_in = __all(inb);
+            if (lane < D) qs_s[par][lane] = qs;
+            if (lane == 63) qs_s[par][63] = all_in ? 1.0 : 0.0;
+            if (lane == 0) ctl_s[par][0] = 0;
+#ifdef ALABI_SPEC_PROF
+            const long long tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+            __syncthreads();                               // barrier A
+            ++rnd;
+            if (!(own_real && par_real)) merge(ld_sc1(pa));   // while the sum runs: one more look
+            __syncthreads();                               // barrier B
+#ifdef ALABI_SPEC_PROF
+            t_round += __builtin_amdgcn_s_memrealtime() - tr0;
+#endif
+            have_sum = true; sum_par = par;
+        }
+        // accept test on the sum of the real proposal, publish the new row, close the item for the other waves
+        {
+            const double sv = __longlong_as_double((long long)real);        // lanes < 32: the own row (lane d: its logp)
+            double prior_q = 0.0;
+            if (p.has_prior) prior_q = normal_prior_sum(consts_s[3], consts_s[4], lane, p.d, qv) + p.prior_const;
+            double lp_new = -INFINITY;
+            if (all_in) lp_new = fma(p.amp, wave_partials_tree(scratch[sum_par], nwc), p.mean) + prior_q;
+            const double lp_old = lane_bcast(sv, p.d);
+            const int acc_flag = (lnfac + lp_new - lp_old > lnu) ? 1 : 0;
+            const double outv = (lane < p.d) ? (acc_flag ? qv : sv) : (acc_flag ? lp_new : lp_old);
+            const unsigned long long outw = (lane <= p.d) ? (unsigned long long)__double_as_longlong(outv)
+                                                          : (unsigned long long)acc_flag;
+            if (lane <= p.d + 1) st_sc1(p.hist + ((size_t)(t + 1) * WT + w) * row + lane, outw);
+#ifdef ALABI_SPEC_PROF
+            const long long t_store = __builtin_amdgcn_s_memrealtime();
+            unsigned long long* tsb = reinterpret_cast<unsigned long long*>(p.dbg) + 16 * 4096;   // publish times [version][walker]
+            if (p.dbg && lane == 0) st_sc1(tsb + (size_t)(t + 1) * WT + w, (unsigned long long)t_store);
+#endif
+            if (lane == 0) ctl_s[rnd & 1][0] = 1;
+            __syncthreads();                               // barrier A of a closing round
+            ++rnd;
+            if (p.dbg && lane == 0) {                      // [0] items [1] rounds [2] guessed rounds [3] items finished on a guess [4] polls
+                long long* c = p.dbg + 16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+                c[0] += 1; c[1] += n_rounds; c[2] += n_spec_rounds; c[3] += last_spec; c[4] += spins;
+#ifdef ALABI_SPEC_PROF
+                // units: 10 ns (s_memrealtime, 100 MHz).  [5] sum detect - publish of the row that arrived last, [6] samples;
+                // [7] store - last detection (items finished on a guess), [8] the same for the others, [9] time in rounds,
+                // [10] item time, [11] how often the partner's row was the last to arrive
+                const long long ts_o = t > 0 ? (long long)ld_sc1(tsb + (size_t)t * WT + w) : 0;
+                const long long ts_p = t + split > 0 ? (long long)ld_sc1(tsb + (size_t)(t + split) * WT + cw) : 0;
+                const bool par_last = t_det_par >= t_det_own;
+                const long long t_last = par_last ? t_det_par : t_det_own, ts_last = par_last ? ts_p : ts_o;
+                if (ts_last > 0 && t_last > 0) { c[5] += t_last - ts_last; c[6] += 1; }
+                if (last_spec) c[7] += t_store - t_last; else c[8] += t_store - t_last;
+                c[9] += t_round; c[10] += __builtin_amdgcn_s_memrealtime() - t_item0; c[11] += par_last;
+#endif
+            }
+        }
+    }
+}
+
 // hist[0] <- (coords, logp); and back: (coords, logp) <- hist[K]
 __global__ void __launch_bounds__(256)
 ens_hist_fill_kernel(unsigned long long* __restrict__ h, size_t n) {
@@ -867,8 +1143,13 @@ bool ens_stream_fits(const alabi_ens* e) { return ens_stream_ppt(e) > 0; }
         default: return ALABI_BAD_ARGUMENT;                           \
     }
 #define ALABI_STREAM_LAUNCH(PPT_, TMAX_)                                                                          \
-    ALABI_STREAM_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type,                                              \
-        hipLaunchKernelGGL((ens_stream_kernel<D, PPT_, TMAX_, GENERIC>), dim3(e->stream_grid, e->E), dim3(T + 128), 0, s, a)))
+    if (spec) {                                                                                                   \
+        ALABI_STREAM_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type,                                          \
+            hipLaunchKernelGGL((ens_spec_kernel<D, PPT_, TMAX_, GENERIC>), dim3(e->W, e->E), dim3(T + 128), 0, s, a))) \
+    } else {                                                                                                      \
+        ALABI_STREAM_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type,                                          \
+            hipLaunchKernelGGL((ens_stream_kernel<D, PPT_, TMAX_, GENERIC>), dim3(e->stream_grid, e->E), dim3(T + 128), 0, s, a))) \
+    }
 
 int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
                       long long* n_accept, hipStream_t s) {
@@ -889,6 +1170,21 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
     // lanes x pairs-per-lane cover Npad/2 point pairs; the launch-per-half-step kernel's lane -> point map (and so its
     // summation order) is reproduced exactly because both run with e->threads compute lanes.
     const int T = e->threads, ppt = ens_stream_ppt(e);
+    // one workgroup per list position of BOTH halves when they all fit on the chip: the speculative kernel
+    const char* spec_env = getenv("ALABI_ENS_SPEC");
+    // Opt-in (ALABI_ENS_SPEC=1): measured on MI355X at the headline size it is bit-identical but not faster than
+    // ens_stream_kernel (2.09 vs 1.99 us per half step: 40 % of the proposals finish on a guess, the publish -> detect
+    // hand-off of 1.09 us stays on the chain either way).
+    const bool spec = e->spec_ok && spec_env && spec_env[0] == '1';
+    e->last_path = spec ? 2 : 1;
+    static long long* dbg_buf = nullptr;
+    const char* dbg_env = getenv("ALABI_SPEC_DBG");
+    if (spec && dbg_env && dbg_env[0] == '1') {
+        const size_t dbg_bytes = 8 * 16 * 4096 + 8 * (size_t)(e->chunk_cap + 1) * e->W * e->E;
+        if (!dbg_buf) (void)hipMalloc(&dbg_buf, 8 * 16 * 4096 + 8 * (size_t)1025 * 4096);
+        (void)hipMemsetAsync(dbg_buf, 0, dbg_bytes, s);
+        a.dbg = dbg_buf;
+    }
     if (T == 256) {
         if (ppt == 1) { ALABI_STREAM_LAUNCH(1, 384); }
         else if (ppt == 2) { ALABI_STREAM_LAUNCH(2, 384); }
@@ -900,6 +1196,23 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
         else if (ppt == 2) { ALABI_STREAM_LAUNCH(2, 640); }
         else return ALABI_BAD_ARGUMENT;
     } else return ALABI_BAD_ARGUMENT;
+    if (a.dbg) {
+        std::vector<long long> h(16 * (size_t)e->W * e->E);
+        (void)hipMemcpyAsync(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        long long tot[12] = {0}, s0[2] = {0, 0}, s1[2] = {0, 0};
+        for (size_t i = 0; i < h.size(); i += 16) for (int k = 0; k < 12; ++k) tot[k] += h[i + k];
+        for (int g = 0; g < e->W; ++g) { long long* t2 = g < n0 ? s0 : s1; t2[0] += h[16 * g + 3]; t2[1] += h[16 * g]; }
+        if (tot[6] > 0)
+            fprintf(stderr, "[ens_spec_kernel prof] publish->detect of the last row %.3f us (%lld samples, partner last %.2f); last detection->store: "
+                            "on a guess %.3f us, otherwise %.3f us; rounds %.3f us/item; item %.3f us\n", 0.01 * tot[5] / tot[6], tot[6],
+                    (double)tot[11] / tot[0], 0.01 * tot[7] / (tot[3] ? tot[3] : 1), 0.01 * tot[8] / ((tot[0] - tot[3]) ? (tot[0] - tot[3]) : 1),
+                    0.01 * tot[9] / tot[0], 0.01 * tot[10] / tot[0]);
+        fprintf(stderr, "[ens_spec_kernel] K=%d items %lld rounds/item %.3f guessed rounds/item %.3f finished-on-a-guess %.3f "
+                        "(set 0: %.3f, set 1: %.3f) polls/item %.2f\n", K, tot[0], (double)tot[1] / tot[0], (double)tot[2] / tot[0],
+                (double)tot[3] / tot[0], s0[1] ? (double)s0[0] / s0[1] : 0.0, s1[1] ? (double)s1[0] / s1[1] : 0.0,
+                (double)tot[4] / tot[0]);
+    }
     hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp,
                        e->hist + (size_t)K * WT * row, WT, e->d, 0);
     if (chain || chain_logp || n_accept)
