@@ -66,6 +66,11 @@ SIGNATURES = {
     "alabi_ens_run": (_i, [_vp, _vp, _vp, _ll, _ll, _i, _d, _vp, _vp, _vp, _vp]),
     "alabi_ens_draw": (_i, [_vp, _ll, _i, _d, _vp]),
     "alabi_ens_half_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "alabi_dist_unique_id": (_i, [_vp]),
+    "alabi_dist_comm_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "alabi_dist_comm_create_callback": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "alabi_dist_comm_destroy": (_i, [_vp]),
+    "alabi_ens_run_sharded": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _i, _d, _vp, _vp, _vp, _vp]),
     "alabi_ens_step_lists": (_i, [_vp, _i, _vp, _pi, _vp]),
     "alabi_ens_step_with_randoms": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp]),
     "alabi_ens_export_draws": (_i, [_vp, _ll, _d, _vp, _pi, _vp, _vp, _vp, _vp, _vp, _vp]),

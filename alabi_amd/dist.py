@@ -26,7 +26,8 @@ import torch.distributed as dist
 
 from . import _lib
 
-__all__ = ["HipBackend", "ShardedEnsemble", "slice_bounds", "gather_replicas"]
+__all__ = ["HipBackend", "ShardedEnsemble", "ShardedRun", "sharded_utility_scan", "reduce_min_index", "slice_bounds",
+           "gather_replicas"]
 
 
 def slice_bounds(n, world, rank):
@@ -131,6 +132,116 @@ class ShardedEnsemble:
             else:
                 dist.all_reduce(n_accept, group=self.group)
         return chain, coords, logp, n_accept
+
+
+class ShardedRun:
+    """The same sharded ensemble with the WHOLE step loop inside the library (alabi_ens_run_sharded): per half step the
+    half-step kernel on this rank's slice, a pack kernel, ONE all-gather and an unpack kernel, all enqueued on the stream --
+    no host read-back between half steps.  The all-gather is RCCL's ncclAllGather on a communicator the library creates
+    itself (rank 0 draws the unique id, torch.distributed only broadcasts its 128 bytes); under a "gloo" process group
+    (test rig: several ranks on ONE GPU, which RCCL refuses) a host callback stands in for it."""
+
+    def __init__(self, sampler, group=None):
+        self.s = sampler
+        sampler._ensure_ens()
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.W, self.d = sampler.nwalkers, sampler.ndim
+        lib = _lib.lib()
+        comm = C.c_void_p()
+        self._cb = None
+        if self.world > 1 and dist.get_backend(group) != "nccl":
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+            world = self.world
+
+            def _allgather(send, recv, count, user, stream):          # device pointers; staged through host memory
+                try:
+                    hip.hipStreamSynchronize(C.c_void_p(stream))
+                    h = np.empty(count, dtype=np.float64)
+                    if hip.hipMemcpy(h.ctypes.data_as(C.c_void_p), C.c_void_p(send), count * 8, 2) != 0:
+                        return 1
+                    out = torch.empty(world * count, dtype=torch.float64)
+                    dist.all_gather_into_tensor(out, torch.from_numpy(h), group=group)
+                    o = out.numpy()
+                    return 0 if hip.hipMemcpy(C.c_void_p(recv), o.ctypes.data_as(C.c_void_p), world * count * 8, 1) == 0 else 1
+                except Exception:  # noqa: BLE001
+                    return 1
+            self._cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p)(_allgather)
+            _lib.check(lib.alabi_dist_comm_create_callback(C.cast(self._cb, C.c_void_p), None, self.rank, self.world,
+                                                           C.byref(comm)), "alabi_dist_comm_create_callback")
+        else:
+            uid = None
+            if self.world > 1:
+                box = [None]
+                if self.rank == 0:
+                    buf = C.create_string_buffer(128)
+                    _lib.check(lib.alabi_dist_unique_id(buf), "alabi_dist_unique_id")
+                    box[0] = buf.raw
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                uid = C.create_string_buffer(box[0], 128)
+            _lib.check(lib.alabi_dist_comm_create(uid, self.rank, self.world, C.byref(comm)), "alabi_dist_comm_create")
+        self._comm = comm
+
+    def __del__(self):
+        try:
+            if getattr(self, "_comm", None) is not None:
+                torch.cuda.synchronize()
+                _lib.lib().alabi_dist_comm_destroy(self._comm)
+        except Exception:  # noqa: BLE001
+            pass
+        self._comm = None
+
+    def run(self, coords, nsteps, step0=0, a=2.0, thin_by=1, store=True):
+        """Returns (chain[nsteps//thin_by, W, d] or None, coords, logp, n_accept) -- identical on every rank."""
+        dev = coords.device
+        coords = coords.clone()
+        logp = self.s.compute_log_prob(coords).clone()
+        n_accept = torch.zeros(self.W, dtype=torch.int64, device=dev)
+        nstore = nsteps // thin_by if store else 0
+        chain = torch.empty((nstore, self.W, self.d), dtype=torch.float64, device=dev) if nstore else None
+        st = _lib.lib().alabi_ens_run_sharded(self.s._ens, self._comm, _lib.ptr(coords), _lib.ptr(logp), int(step0), int(nsteps),
+                                              int(thin_by), float(a), _lib.ptr(chain), None, _lib.ptr(n_accept),
+                                              _lib.current_stream())
+        _lib.check(st, "alabi_ens_run_sharded")
+        return chain, coords, logp, n_accept
+
+
+def reduce_min_index(val, idx, group=None):
+    """All-reduce of ONE (value, global index) pair: the smallest value wins, ties go to the smallest index; a rank
+    without a finite candidate contributes (+inf, -1).  Returns (value, index) on every rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(val), int(idx)
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    pair = torch.tensor([float(val), float(idx)], dtype=torch.float64, device=dev)   # indices < 2^53 are exact in fp64
+    allp = torch.empty(2 * world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(allp, pair, group=group)
+    allp = allp.cpu().numpy().reshape(world, 2)
+    best_v, best_i = np.inf, -1
+    for v, i in allp:
+        if i >= 0 and (v < best_v or (v == best_v and i < best_i)):
+            best_v, best_i = float(v), int(i)
+    return best_v, best_i
+
+
+def sharded_utility_scan(scan_fn, M, group=None):
+    """Candidate scan sharded over the ranks (BASELINE.json config C5: BAPE over 10^6
+    candidates on 8 GPUs).  The M candidates are partitioned into contiguous slices; every rank holds the (replicated,
+    redundantly factorised) GP and scores ITS slice with ``scan_fn(begin, end) -> (best_value, best_local_index)``
+    (product: alabi_amd.utility.utility_scan on candidates[begin:end]); ONE (value, global index) pair is all-reduced.
+    Returns (value, global index, (begin, end)) -- identical value / index on every rank; index -1 when no candidate
+    is finite.  The reference has no equivalent (its parallel axis is a process pool over scipy restarts,
+    alabi/utility.py:1030-1163)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    b, e = slice_bounds(int(M), world, rank)
+    val, li = (np.inf, -1) if e == b else scan_fn(b, e)
+    gi = b + int(li) if (li is not None and int(li) >= 0 and np.isfinite(val)) else -1
+    v, i = reduce_min_index(val if gi >= 0 else np.inf, gi, group)
+    return v, i, (b, e)
 
 
 def gather_replicas(samples, group=None):

@@ -262,12 +262,12 @@ def main():
 
     shard = args.mode == "shard" and world > 1
     if shard:
-        from alabi_amd.dist import HipBackend, ShardedEnsemble
+        from alabi_amd.dist import ShardedRun
         Wtot = W * world
         rngp = np.random.RandomState(1000 + d)
         p0 = rngp.uniform(cfg["bounds"][:, 0] * 0.5, cfg["bounds"][:, 1] * 0.5, (Wtot, d))
         sampler = EnsembleSampler(Wtot, d, gp, cfg["y"], cfg["bounds"], seed=2026)
-        ens = ShardedEnsemble(HipBackend(sampler))
+        ens = ShardedRun(sampler)          # the whole step loop in the library, one ncclAllGather per half step on the stream
         state = {"coords": torch.as_tensor(p0, device="cuda"), "step": 0}
 
         def one_step():
@@ -320,11 +320,11 @@ def main():
     shard_info = None
     if world > 1 and not shard and args.shard_extra:
         try:
-            from alabi_amd.dist import HipBackend, ShardedEnsemble
+            from alabi_amd.dist import ShardedRun
             Wtot = W * world
             p0s = np.random.RandomState(5).uniform(cfg["bounds"][:, 0] * 0.5, cfg["bounds"][:, 1] * 0.5, (Wtot, d))
             s2 = EnsembleSampler(Wtot, d, gp, cfg["y"], cfg["bounds"], seed=99)
-            ens2 = ShardedEnsemble(HipBackend(s2))
+            ens2 = ShardedRun(s2)
             c0 = torch.as_tensor(p0s, device="cuda")
             ens2.run(c0, 8, store=False)
             fence()
@@ -334,7 +334,7 @@ def main():
             fence()
             dt2 = time.perf_counter() - t1
             shard_info = {"walkers": Wtot, "steps": nst, "samples_per_s": Wtot * nst / dt2,
-                          "us_per_half_step": 1e6 * dt2 / (2 * nst), "collective": "all_gather_into_tensor per half step"}
+                          "us_per_half_step": 1e6 * dt2 / (2 * nst), "collective": "ncclAllGather per half step, enqueued by alabi_ens_run_sharded"}
         except Exception as ex:  # noqa: BLE001
             shard_info = {"error": repr(ex)[:300]}
 

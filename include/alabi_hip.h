@@ -209,6 +209,23 @@ int alabi_ens_propose(alabi_ens* ens, const double* coords, int t, int split, in
                       double* q, double* like, void* stream);
 int alabi_ens_accept(alabi_ens* ens, double* coords, double* logp, int t, int split,
                      const double* q, const double* lp_new, long long* n_accept, void* stream);
+/* ONE ensemble sharded over the GPUs of a node with the whole step loop in the library (n_ensembles == 1): each rank
+ * applies every half step to its slice of the active list and the updated (coords, logp) rows are exchanged with one
+ * all-gather per half step, enqueued on `stream` (RCCL ncclAllGather over xGMI; librccl.so is loaded with dlopen on first
+ * use).  Replaces the reference's process pool under emcee (alabi/core.py:2300, :2322).  Every rank passes the same
+ * initial coords / logp / step0 and ends with the same coords / logp / chain; n_accept [W] is ADDED to (summed over ranks).
+ * alabi_dist_unique_id: rank 0 obtains 128 bytes and distributes them (e.g. torch.distributed broadcast), then every rank
+ * calls alabi_dist_comm_create with them (nranks == 1 needs no id).  The *_callback form carries a host function instead
+ * of RCCL: the test rig for several ranks on one GPU (it must complete the exchange before returning). */
+typedef struct alabi_comm alabi_comm;
+typedef int (*alabi_allgather_fn)(const double* send_dev, double* recv_dev, long long count_per_rank, void* user, void* stream);
+int alabi_dist_unique_id(void* id_out /* host, 128 bytes */);
+int alabi_dist_comm_create(const void* id /* host, 128 bytes */, int rank, int nranks, alabi_comm** out);
+int alabi_dist_comm_create_callback(alabi_allgather_fn fn, void* user, int rank, int nranks, alabi_comm** out);
+int alabi_dist_comm_destroy(alabi_comm* comm);
+int alabi_ens_run_sharded(alabi_ens* ens, alabi_comm* comm, double* coords, double* logp, long long step0,
+                          long long nsteps, int thin_by, double a, double* chain, double* chain_logp,
+                          long long* n_accept, void* stream);
 /* copy of the walker lists of drawn local step t: order_out[W] int32 (device), n0 (host). */
 int alabi_ens_step_lists(alabi_ens* ens, int t, int* order_out, int* n0, void* stream);
 

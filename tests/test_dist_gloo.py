@@ -100,3 +100,56 @@ def test_slice_bounds_cover_everything():
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
             sizes = [e - b for b, e in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _scan_worker(rank, world, port, M, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from alabi_amd.dist import sharded_utility_scan
+    from oracle.utility_oracle import utility_batch
+    cand, mu, var, bounds = _scan_problem(M)
+
+    def scan(b, e):                                  # stand-in for utility_scan on this rank's slice (NumPy oracle)
+        u = utility_batch("bape", mu[b:e], var[b:e], cand[b:e], bounds)
+        fin = np.isfinite(u)
+        if not fin.any():
+            return np.inf, -1
+        i = int(np.flatnonzero(fin)[np.argmin(u[fin])])
+        return float(u[i]), i
+
+    out[rank] = sharded_utility_scan(scan, M)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _scan_problem(M):
+    rs = np.random.RandomState(11)
+    cand = rs.uniform(-1.2, 1.2, (M, 3))             # some outside the unit box -> +inf utility
+    mu = rs.normal(size=M)
+    var = rs.uniform(0.01, 2.0, M)
+    if M > 40:
+        cand[:M // 3] = 5.0                          # the whole first slice of a 3-rank run is outside the box
+        mu[M // 2] = mu[M - 2] = 50.0; var[M // 2] = var[M - 2] = 1.0; cand[M // 2] = cand[M - 2] = 0.1   # an exact tie across ranks
+    return cand, mu, var, np.array([[-1.0, 1.0]] * 3)
+
+
+@pytest.mark.parametrize("world,M", [(2, 1001), (3, 90), (2, 1)])
+def test_sharded_candidate_scan_matches_single_process(world, M):
+    """C5's candidate-scan shard: partition M over the ranks, all-reduce ONE (value, global index) pair; every rank ends
+    with the arg-min of the full scan (ties -> smallest index; a rank without finite candidates contributes nothing)."""
+    from oracle.utility_oracle import utility_batch
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_scan_worker, args=(world, _free_port(), M, out), nprocs=world, join=True)
+    cand, mu, var, bounds = _scan_problem(M)
+    u = utility_batch("bape", mu, var, cand, bounds)
+    fin = np.isfinite(u)
+    ref_i = int(np.flatnonzero(fin)[np.argmin(u[fin])]) if fin.any() else -1
+    cover = []
+    for r in range(world):
+        v, i, (b, e) = out[r]
+        assert i == ref_i and (i < 0 or v == u[ref_i]), (r, v, i, ref_i)
+        cover.append((b, e))
+    assert cover[0][0] == 0 and cover[-1][1] == M and all(cover[k][1] == cover[k + 1][0] for k in range(world - 1))

@@ -30,6 +30,17 @@ def _worker(rank, world, port, W, nsteps, out):
     ens = ShardedEnsemble(HipBackend(sampler))
     p0 = np.random.RandomState(9).uniform(-2, 2, (W, 4))
     chain, coords, logp, nacc = ens.run(torch.as_tensor(p0, device="cuda"), nsteps, step0=0)
+    # the same run with the whole step loop inside the library (alabi_ens_run_sharded; host callback instead of RCCL here)
+    from alabi_amd.dist import ShardedRun, sharded_utility_scan
+    from alabi_amd.utility import utility_scan
+    run_c = ShardedRun(sampler)
+    chain_c, coords_c, logp_c, nacc_c = run_c.run(torch.as_tensor(p0, device="cuda"), nsteps, step0=0, thin_by=1)
+    assert torch.equal(chain_c, chain) and torch.equal(coords_c, coords) and torch.equal(logp_c, logp) and torch.equal(nacc_c, nacc)
+    # candidate scan sharded over the two ranks: one (value, index) pair all-reduced
+    cand = torch.as_tensor(np.random.RandomState(3).uniform(-3.2, 3.2, (5001, 4)), device="cuda")
+    full = utility_scan(gp, y, cand, bounds, "bape")
+    v, gi, (b, e) = sharded_utility_scan(lambda b_, e_: utility_scan(gp, y, cand[b_:e_], bounds, "bape")[1:3], cand.shape[0])
+    assert gi == full[2] and v == full[1], (rank, v, gi, full[1:])
     out[rank] = (chain.cpu().numpy(), nacc.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -58,3 +69,25 @@ def test_two_ranks_match_single_process_hip_chain():
         c_r, n_r = out[r]
         assert np.array_equal(c_r, chain), f"rank {r}"
         assert np.array_equal(n_r, ref._naccept.cpu().numpy())
+
+
+def test_sharded_run_single_rank_and_rccl_loads():
+    """nranks == 1 through the C loop equals the plain run; librccl.so resolves (ncclGetUniqueId returns 128 bytes)."""
+    import ctypes as C
+    import torch
+    from conftest import make_problem
+    from alabi_amd import EnsembleSampler, HipGP, _lib
+    from alabi_amd.dist import ShardedRun
+    X, y, h = make_problem(300, 4, 7)
+    gp = HipGP(4, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); gp.compute(X)
+    bounds = np.array([[-3.0, 3.0]] * 4)
+    W, nsteps = 31, 75
+    p0 = np.random.RandomState(9).uniform(-2, 2, (W, 4))
+    ref = EnsembleSampler(W, 4, gp, y, bounds, seed=77); ref.run_mcmc(p0, nsteps, thin_by=3)
+    s = EnsembleSampler(W, 4, gp, y, bounds, seed=77)
+    chain, coords, logp, nacc = ShardedRun(s).run(torch.as_tensor(p0, device="cuda"), nsteps, thin_by=3)
+    assert np.array_equal(chain.cpu().numpy(), ref.get_chain())
+    assert np.array_equal(nacc.cpu().numpy(), ref._naccept.cpu().numpy())
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.lib().alabi_dist_unique_id(buf), "alabi_dist_unique_id")
+    assert any(b != 0 for b in buf.raw)
