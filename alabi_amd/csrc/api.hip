@@ -132,6 +132,7 @@ int alabi_gp_destroy(alabi_gp* gp) {
     if (!gp) return ALABI_OK;
     if (gp->L) (void)hipFree(gp->L);
     if (gp->Xt) (void)hipFree(gp->Xt);
+    if (gp->Xa) (void)hipFree(gp->Xa);
     if (gp->y) (void)hipFree(gp->y);
     if (gp->alpha) (void)hipFree(gp->alpha);
     if (gp->dinv) (void)hipFree(gp->dinv);

@@ -65,6 +65,8 @@ struct alabi_gp {
     // device buffers
     double* L = nullptr;      // [n_cap, n_cap] row-major, lower triangle holds chol(K)
     double* Xt = nullptr;     // [d, n_cap]  scaled, transposed training inputs (SoA)
+    double* Xa = nullptr;     // [round_up(d + 2, 4), n_cap] augmented rows (Xt, -|x|^2 / 2, 1, 0..) for the matrix-core predict-mean kernel
+    long long xa_gen = -1;    // factor_gen the rows belong to (built lazily)
     double* y = nullptr;      // [n_cap]
     double* alpha = nullptr;  // [n_cap]
     double* dinv = nullptr;   // [n_cap] 1 / L_ii (every triangular solve multiplies by it)

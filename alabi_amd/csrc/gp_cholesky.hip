@@ -227,15 +227,25 @@ trsm_panel_kernel(double* __restrict__ A, int ld, int kb, const double* __restri
 // C[bi,bj] -= P[bi] * P[bj]^T with P[b] = A[b-block rows, kb-block cols].  Workgroup 0 owns the tile (kb+1, kb+1), which is
 // complete after this update: it factorises it on the spot (one wave, potrf_tile_lds), so the next block step starts with
 // its panel solve and the diagonal factorisation costs no launch, no reload and overlaps the other tiles' updates.
+// jc > 0 restricts the update to the first jc block columns of the trailing matrix (the rest of a 256-column panel; the
+// columns beyond it receive the whole panel at once from syrk_panel_kernel): tiles are then numbered column by column.
 __global__ void __launch_bounds__(256)
-syrk_update_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info, double* __restrict__ dinv) {
+syrk_update_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info, double* __restrict__ dinv, int jc, int T) {
     __shared__ double Pi[64][66];
     __shared__ double Pj[64][66];
     int t = blockIdx.x;
-    int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while (ti * (ti + 1) / 2 > t) --ti;
-    int tj = t - ti * (ti + 1) / 2;
+    int ti, tj;
+    if (jc > 0) {
+        tj = 0;
+        int off = 0;
+        while (tj + 1 < jc && t >= off + (T - tj)) { off += T - tj; ++tj; }
+        ti = tj + (t - off);
+    } else {
+        ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while (ti * (ti + 1) / 2 > t) --ti;
+        tj = t - ti * (ti + 1) / 2;
+    }
     const int bi = kb + 1 + ti, bj = kb + 1 + tj;
     const int tid = threadIdx.x;
     const double* Ai = A + (size_t)(bi * 64) * ld + kb * 64;
@@ -288,15 +298,195 @@ syrk_update_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ inf
         for (int i = 0; i < 4; ++i) C[(size_t)(lk + 4 * i) * ld + 16 * n + lr] = acc[n][i];
 }
 
+// Trailing update with a whole 256-column panel: C[I,J] -= P_I P_J^T for 128 x 128 tiles (I >= J) of the matrix behind the
+// panel, P_X = A[rows of tile X, panel columns] (128 x KP, KP = 64 * width of the panel in blocks <= 256).  Rank-64 updates
+// re-read and re-write every trailing tile once per block column (5-7x the algorithmic traffic); here a
+// tile is read and written ONCE per four block columns and each staged panel byte feeds a 128-wide output: 11 flop per
+// byte of L2 traffic instead of 4.  Four wavefronts, each owns a 64 x 64 quadrant = 4 x 4 accumulator tiles of
+// v_mfma_f64_16x16x4 (128 VGPRs); the panel rows are staged 16 columns at a time through two LDS buffers (row stride 18
+// doubles: conflict-free ds_read_b64 for the fragment layout), the next slice is fetched into registers while the current
+// one is multiplied; one barrier per slice.  Tile columns [tc0, tc1) of the trailing matrix are processed (look-ahead: the
+// columns of the next panel on the main stream, the rest on a second stream).
+__global__ void __launch_bounds__(256)
+syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int row0, int tc0, int tc1, int ntr,
+                  int* __restrict__ info, double* __restrict__ dinv) {
+    __shared__ __attribute__((aligned(16))) double Ps[2][2][128][18];   // [buffer][I / J][row][k]
+    // tile (ti, tj), tc0 <= tj < tc1, tj <= ti < ntr, numbered column by column
+    int t = blockIdx.x, tj = tc0, off = 0;
+    while (tj + 1 < tc1 && t >= off + (ntr - tj)) { off += ntr - tj; ++tj; }
+    const int ti = tj + (t - off);
+    const int ri = row0 + 128 * ti, rj = row0 + 128 * tj;            // first row of P_I / P_J (= first column of the C tile)
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+    const int wr = w >> 1, wc = w & 1;
+    // staging map: thread -> (row r8 + 32 pass, 2 consecutive k), 8 threads per 128-byte row slice
+    const int sr = tid >> 3, sk = (tid & 7) * 2;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2 gi[4], gj[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = sr + 32 * ps;
+            gi[ps] = (ri + r < n) ? *reinterpret_cast<const f64x2*>(A + (size_t)(ri + r) * ld + col0 + k0 + sk) : f64x2{0.0, 0.0};
+            gj[ps] = (rj + r < n) ? *reinterpret_cast<const f64x2*>(A + (size_t)(rj + r) * ld + col0 + k0 + sk) : f64x2{0.0, 0.0};
+        }
+    };
+    auto stage = [&](int b) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = sr + 32 * ps;
+            *reinterpret_cast<f64x2*>(&Ps[b][0][r][sk]) = gi[ps];
+            *reinterpret_cast<f64x2*>(&Ps[b][1][r][sk]) = gj[ps];
+        }
+    };
+    fetch(0);
+    // accumulators start from C (rows ri + 64 wr + 16 m + lk + 4 i, columns rj + 64 wc + 16 nn + lr)
+    v4f64 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = ri + 64 * wr + 16 * m + lk + 4 * i, c = rj + 64 * wc + 16 * nn + lr;
+                acc[m][nn][i] = (r < n && c < n && (c >> 6) <= (r >> 6)) ? A[(size_t)r * ld + c] : 0.0;
+            }
+    stage(0);
+    __syncthreads();
+    const int nslices = kp / 16;
+    for (int sl = 0; sl < nslices; ++sl) {
+        const int b = sl & 1;
+        if (sl + 1 < nslices) fetch(16 * (sl + 1));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double a[4], bb[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = -Ps[b][0][64 * wr + 16 * m + lr][4 * kk + lk];
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) bb[nn] = Ps[b][1][64 * wc + 16 * nn + lr][4 * kk + lk];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], bb[nn], acc[m][nn], 0, 0, 0);
+        }
+        if (sl + 1 < nslices) stage(b ^ 1);
+        __syncthreads();
+    }
+    // The first tile holds the diagonal block of the NEXT panel in the quadrant of wave 0: it is complete now, so it is
+    // factorised on the spot (potrf_tile_lds_wg, all four waves) instead of by a launch of its own.
+    if (t == 0 && tc0 == 0 && dinv) {
+        double (*Ls)[66] = reinterpret_cast<double (*)[66]>(&Ps[0][0][0][0]);     // 64 x 66 doubles: fits the staging buffers
+        if (w == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Ls[16 * m + lk + 4 * i][16 * nn + lr] = acc[m][nn][i];
+        }
+        __syncthreads();
+        const double rinv = potrf_tile_lds_wg<66>(Ls, tid, row0 / 64, info);
+        if (w == 0) {
+            dinv[row0 + l] = rinv;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[m][nn][i] = Ls[16 * m + lk + 4 * i][16 * nn + lr];
+        }
+    }
+    // only block columns <= block rows belong to the factorisation: the upper 64-block of a diagonal tile is left alone
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = ri + 64 * wr + 16 * m + lk + 4 * i, c = rj + 64 * wc + 16 * nn + lr;
+                if (r < n && c < n && (c >> 6) <= (r >> 6)) A[(size_t)r * ld + c] = acc[m][nn][i];
+            }
+}
+
+static int tiles_in_cols(int ntr, int tc0, int tc1) {
+    int n = 0;
+    for (int tj = tc0; tj < tc1; ++tj) n += ntr - tj;
+    return n;
+}
+
 int launch_cholesky(alabi_gp* gp, hipStream_t s) {
     const int ld = gp->Npad, nb = gp->Npad / 64;
     ALABI_HIP_CHECK(hipMemsetAsync(gp->info, 0, sizeof(int), s));
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, s, gp->L, ld, 0, gp->info, gp->dinv);
-    for (int kb = 0; kb + 1 < nb; ++kb) {
-        const int T = nb - kb - 1;
-        hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(256), 0, s, gp->L, ld, kb, gp->dinv);
-        hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, s, gp->L, ld, kb, gp->info, gp->dinv);   // + potrf of block kb+1
+    // Block columns per panel (0: rank-64 updates of the whole trailing matrix).  Measured on MI355X (tools/prof_cholesky.py):
+    // the panel path wins from about N = 8000 on (N = 10000: 14.1 -> 12.3 ms); below that the extra launches per panel cost
+    // more than the trailing traffic they save (N = 5000: 3.1 vs 3.8 ms).
+    int panel = nb >= 128 ? 4 : 0;
+    if (const char* env = getenv("ALABI_CHOL_PANEL")) { const int v = atoi(env); if (v == 0 || v == 2 || v == 4) panel = v; }
+    if (panel == 0) {
+        for (int kb = 0; kb + 1 < nb; ++kb) {
+            const int T = nb - kb - 1;
+            hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(256), 0, s, gp->L, ld, kb, gp->dinv);
+            hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, s, gp->L, ld, kb, gp->info, gp->dinv, 0, T);   // + potrf of block kb+1
+        }
+        ALABI_LAUNCH_CHECK();
+        return ALABI_OK;
     }
+    // Panels of `panel` block columns.  Inside a panel: trsm of block column kb, rank-64 update of the REST OF THE PANEL only
+    // (with the factorisation of the next diagonal block fused in).  Behind it: one rank-(64 panel) update of the trailing
+    // matrix, split for look-ahead -- the tile columns of the next panel on the caller's stream (the next panel's chain of
+    // small launches waits only for them), everything further right on a second stream, overlapping that chain.
+    // (per host thread: the cross-validation search factorises on several threads and streams at once)
+    static thread_local hipStream_t side = nullptr;
+    static thread_local hipEvent_t ev_panel[2] = {nullptr, nullptr}, ev_rest[2] = {nullptr, nullptr};
+    const char* la_env = getenv("ALABI_CHOL_LOOKAHEAD");
+    const bool lookahead = !(la_env && la_env[0] == '0');
+    if (lookahead && !side) {
+        ALABI_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            ALABI_HIP_CHECK(hipEventCreateWithFlags(&ev_panel[i], hipEventDisableTiming));
+            ALABI_HIP_CHECK(hipEventCreateWithFlags(&ev_rest[i], hipEventDisableTiming));
+        }
+    }
+    bool rest_pending = false;
+    int pi = 0;
+    for (int p0 = 0; p0 < nb; p0 += panel, ++pi) {
+        const int pe = p0 + panel < nb ? p0 + panel : nb;
+        for (int kb = p0; kb < pe; ++kb) {
+            const int T = nb - kb - 1;
+            if (T == 0) break;
+            hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(256), 0, s, gp->L, ld, kb, gp->dinv);
+            const int jc = pe - kb - 1;
+            if (jc > 0) {
+                int tiles = 0;
+                for (int tj = 0; tj < jc; ++tj) tiles += T - tj;
+                hipLaunchKernelGGL(syrk_update_kernel, dim3(tiles), dim3(256), 0, s, gp->L, ld, kb, gp->info, gp->dinv, jc, T);
+            }
+        }
+        if (pe >= nb) break;
+        const int row0 = 64 * pe, ntr = (gp->Npad - row0 + 127) / 128, kp = 64 * (pe - p0);
+        const int next_tc = (panel * 64) / 128;          // tile columns that make up the next panel
+        const int tc_split = next_tc < ntr ? next_tc : ntr;
+        if (lookahead) {
+            // the rest of the PREVIOUS panel's update touched the tiles we are about to update: wait for it
+            if (rest_pending) ALABI_HIP_CHECK(hipStreamWaitEvent(s, ev_rest[(pi + 1) & 1], 0));
+            ALABI_HIP_CHECK(hipEventRecord(ev_panel[pi & 1], s));                       // panel pi is final
+            hipLaunchKernelGGL(syrk_panel_kernel, dim3(tiles_in_cols(ntr, 0, tc_split)), dim3(256), 0, s, gp->L, ld, gp->Npad, 64 * p0, kp,
+                               row0, 0, tc_split, ntr, gp->info, gp->dinv);
+            if (tc_split < ntr) {
+                ALABI_HIP_CHECK(hipStreamWaitEvent(side, ev_panel[pi & 1], 0));
+                hipLaunchKernelGGL(syrk_panel_kernel, dim3(tiles_in_cols(ntr, tc_split, ntr)), dim3(256), 0, side, gp->L, ld, gp->Npad,
+                                   64 * p0, kp, row0, tc_split, ntr, ntr, gp->info, (double*)nullptr);
+                ALABI_HIP_CHECK(hipEventRecord(ev_rest[pi & 1], side));
+                rest_pending = true;
+            } else {
+                rest_pending = false;
+            }
+        } else {
+            hipLaunchKernelGGL(syrk_panel_kernel, dim3(tiles_in_cols(ntr, 0, ntr)), dim3(256), 0, s, gp->L, ld, gp->Npad, 64 * p0, kp, row0,
+                               0, ntr, ntr, gp->info, gp->dinv);
+        }
+    }
+    if (lookahead && rest_pending) ALABI_HIP_CHECK(hipStreamWaitEvent(s, ev_rest[(pi + 1) & 1], 0));
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

@@ -60,6 +60,29 @@ __device__ inline double exp_neg_half(double r2) {
     return ldexp(p, (int)n);
 }
 
+// exp(x) for an argument that is already -r2/2 (the matrix-core predict path forms it as one dot product): the same
+// reduction and polynomial as exp_neg_half, without the multiply.  x may exceed 0 by rounding; large |x| underflows to 0.
+__device__ inline double exp_direct(double x) {
+    const double n = rint(x * 1.4426950408889634);
+    double r = fma(n, -0x1.62e42fee00000p-1, x);
+    r = fma(n, -0x1.a39ef35793c76p-33, r);
+    double p = 1.6059043836821613e-10;
+    p = fma(p, r, 2.08767569878681e-09);
+    p = fma(p, r, 2.505210838544172e-08);
+    p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 0.0001984126984126984);
+    p = fma(p, r, 0.001388888888888889);
+    p = fma(p, r, 0.008333333333333333);
+    p = fma(p, r, 0.041666666666666664);
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
 // GENERIC = false compiles the squared-exponential alone (no run-time switch in the hot loops).
 template <bool GENERIC = true>
 __device__ inline double radial(double r2, KernelFn kf) {

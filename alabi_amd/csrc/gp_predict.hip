@@ -863,10 +863,135 @@ predict_var_w_final_kernel(const double* __restrict__ partial, int parts, long l
 
 static int ensure_mupart(alabi_gp* gp, size_t bytes, hipStream_t s);
 
+// ---- predict-mean with the dot products on the matrix cores (large batches) -------------------------------------
+// mu*(q) = amp sum_n alpha_n f(r2(q, x_n)) + m (reference call sites alabi/core.py:85, :1812).  With the rows
+// x' = (x, -|x|^2/2, 1) and q' = (q, 1, -|q|^2/2) the product q'.x' IS -r2/2, the argument of the squared-exponential:
+// v_mfma_f64_16x16x4 forms it for 16 queries x 16 training points per instruction (ceil((d+2)/4) of them per tile) while the
+// vector unit only evaluates exp and the alpha FMA -- 21 instead of 41 fp64 VALU instructions per kernel evaluation, and
+// the two pipes run side by side.  One wavefront owns 64 queries (four 16-row A operands kept in registers) and walks over
+// the training points 16 at a time (B operand and alpha: one double per lane per k-step, L2-resident); a lane ends with
+// the partial sums of 16 queries over its point column, folded across the 16 lanes of its row with DPP adds.
+__global__ void __launch_bounds__(256)
+build_xa_kernel(const double* __restrict__ Xt, int Npad, int d, int rows, double* __restrict__ Xa) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= Npad) return;
+    double xx = 0.0;
+    for (int k = 0; k < d; ++k) {
+        const double v = Xt[(size_t)k * Npad + n];
+        Xa[(size_t)k * Npad + n] = v;
+        xx = fma(v, v, xx);
+    }
+    Xa[(size_t)d * Npad + n] = -0.5 * xx;
+    Xa[(size_t)(d + 1) * Npad + n] = 1.0;
+    for (int k = d + 2; k < rows; ++k) Xa[(size_t)k * Npad + n] = 0.0;
+}
+
+template <int KS, bool GENERIC>
+__global__ void __launch_bounds__(256)
+predict_mean_mfma_kernel(const double* __restrict__ Xa, const double* __restrict__ alpha, int Npad,
+                         const double* __restrict__ Xs, int d, long long M, DimVec inv_len, double amp, double mean,
+                         KernelFn kf, double* __restrict__ mu) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const long long q0 = ((long long)blockIdx.x * 4 + wv) * 64;
+    if (q0 >= M) return;
+    // A operands: query row lr of tile qt, coordinate 4 s + lk of k-step s (the augmented row q' = (q / l, 1, -|q / l|^2 / 2))
+    double a[4][KS];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const long long m = q0 + 16 * qt + lr;
+        const bool valid = m < M;
+        double qq = 0.0;
+        for (int k = 0; k < d; ++k) {
+            const double v = valid ? Xs[m * d + k] * inv_len.v[k] : 0.0;
+            qq = fma(v, v, qq);
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 4 * s + lk;
+            double v = 0.0;
+            if (valid) v = (c < d) ? Xs[m * d + c] * inv_len.v[c] : (c == d) ? 1.0 : (c == d + 1) ? -0.5 * qq : 0.0;
+            a[qt][s] = v;
+        }
+    }
+    double sum[4][4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sum[qt][i] = 0.0;
+    const double* xb = Xa + (size_t)lk * Npad + lr;       // B operand: point column lr of the tile, coordinate 4 s + lk
+    for (int n0 = 0; n0 < Npad; n0 += 16) {
+        double b[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) b[s] = xb[(size_t)(4 * s) * Npad + n0];
+        const double al = alpha[n0 + lr];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qt][s], b[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                 // C/D layout: row (query) lk + 4 i, column (point) lr
+                const double f = GENERIC ? radial<true>(fmax(-2.0 * acc[i], 0.0), kf) : exp_direct(acc[i]);
+                sum[qt][i] = fma(al, f, sum[qt][i]);
+            }
+        }
+    }
+    // fold the 16 point columns of every query: the 16 lanes of a DPP row share lk
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double v = sum[qt][i];
+            v += dpp_move<0x111, 0xf>(v);
+            v += dpp_move<0x112, 0xf>(v);
+            v += dpp_move<0x114, 0xf>(v);
+            v += dpp_move<0x118, 0xf>(v);
+            const long long m = q0 + 16 * qt + lk + 4 * i;
+            if (lr == 15 && m < M) mu[m] = fma(amp, v, mean);
+        }
+}
+
+static int ensure_xa(alabi_gp* gp, hipStream_t s) {
+    const int rows = round_up(gp->d + 2, 4);
+    if (!gp->Xa) ALABI_HIP_CHECK(hipMalloc(&gp->Xa, (size_t)rows * gp->n_cap * sizeof(double)));
+    if (gp->xa_gen != gp->factor_gen) {
+        hipLaunchKernelGGL(build_xa_kernel, dim3((gp->Npad + 255) / 256), dim3(256), 0, s, gp->Xt, gp->Npad, gp->d, rows, gp->Xa);
+        gp->xa_gen = gp->factor_gen;
+    }
+    return ALABI_OK;
+}
+
+#define ALABI_DISPATCH_KS(KS_, ...)                                                             \
+    switch (KS_) {                                                                              \
+        case 1: { constexpr int KS = 1; __VA_ARGS__; } break;                                   \
+        case 2: { constexpr int KS = 2; __VA_ARGS__; } break;                                   \
+        case 3: { constexpr int KS = 3; __VA_ARGS__; } break;                                   \
+        case 4: { constexpr int KS = 4; __VA_ARGS__; } break;                                   \
+        case 5: { constexpr int KS = 5; __VA_ARGS__; } break;                                   \
+        case 6: { constexpr int KS = 6; __VA_ARGS__; } break;                                   \
+        case 7: { constexpr int KS = 7; __VA_ARGS__; } break;                                   \
+        case 8: { constexpr int KS = 8; __VA_ARGS__; } break;                                   \
+        default: return ALABI_BAD_ARGUMENT;                                                     \
+    }
+
 int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu, hipStream_t s) {
     if (M <= 0) return ALABI_OK;
     const int db = dim_bucket(gp->d);
     const double amp = exp(gp->log_amp);
+    const char* mf = getenv("ALABI_PM_MFMA");
+    // batches that fill the chip with 256-query workgroups and d + 2 <= 32: the matrix-core kernel
+    if (M >= 32768 && gp->d + 2 <= 32 && !(mf && mf[0] == '0')) {
+        int st = ensure_xa(gp, s);
+        if (st != ALABI_OK) return st;
+        const int ks = (gp->d + 2 + 3) / 4;
+        const long long wgs = (M + 255) / 256;
+        if (wgs > 0x7fffffffLL) return ALABI_BAD_ARGUMENT;
+        ALABI_DISPATCH_KS(ks, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_mean_mfma_kernel<KS, GENERIC>), dim3((unsigned)wgs),
+            dim3(256), 0, s, gp->Xa, gp->alpha, gp->Npad, Xs, gp->d, M, gp->inv_len, amp, gp->mean, gp->kf, mu)));
+        ALABI_LAUNCH_CHECK();
+        return ALABI_OK;
+    }
     if (M <= 4096) {
         ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(predict_mean_rowwise_kernel<D>, dim3((unsigned)M), dim3(256), 0, s,
                                                   gp->Xt, gp->alpha, gp->Npad, Xs, gp->d, gp->inv_len, amp,

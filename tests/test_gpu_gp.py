@@ -542,3 +542,57 @@ def test_medium_batches_groups_and_split_prepass(N, d):
     mu = g.predict(y, Xs, return_cov=False)
     mu_o = o.predict(y, Xs)
     assert np.max(np.abs(mu - mu_o) / (np.abs(mu_o) + 1)) <= 1e-9
+
+
+@pytest.mark.parametrize("d,N,kernel", [(10, 2000, "ExpSquaredKernel"), (2, 130, "ExpSquaredKernel"), (20, 700, "ExpSquaredKernel"),
+                                        (5, 500, "Matern52Kernel"), (30, 300, "RationalQuadraticKernel")])
+def test_predict_mean_matrix_core_path(torch_gpu, monkeypatch, d, N, kernel):
+    """Batches of >= 32768 queries form q.x on the matrix cores (predict_mean_mfma_kernel, the exponent as ONE augmented dot
+    product): against the vector kernel on every point and against the oracle on a slice; ragged last workgroup included."""
+    import torch
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    X, y, h = make_problem(N, d, 40 + d)
+    kw = dict(kernel=kernel, log_alpha=0.4)
+    g = HipGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"], **kw); g.compute(X)
+    M = 32768 + 4 * 64 + 37
+    Xs = np.random.RandomState(d).uniform(-3.2, 3.2, (M, d))
+    Xs[:N] = X                                                   # queries ON training points: r2 = 0 exactly in exact arithmetic
+    mu_m = g.predict(y, Xs, return_cov=False)
+    monkeypatch.setenv("ALABI_PM_MFMA", "0")
+    mu_v = g.predict(y, Xs, return_cov=False)
+    monkeypatch.delenv("ALABI_PM_MFMA")
+    assert mu_m.shape == mu_v.shape == (M,)
+    assert np.max(np.abs(mu_m - mu_v) / (np.abs(mu_v) + 1)) <= 1e-9
+    o = OracleGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"], **kw).compute(X)
+    pick = np.concatenate([np.arange(64), np.random.RandomState(1).choice(M, 400, replace=False), [M - 1]])
+    mu_o = o.predict(y, Xs[pick])
+    assert np.max(np.abs(mu_m[pick] - mu_o) / (np.abs(mu_o) + 1)) <= 1e-8
+
+
+@pytest.mark.parametrize("N,panel", [(705, "4"), (1500, "4"), (1100, "2"), (3200, "4")])
+def test_cholesky_panel_path(torch_gpu, monkeypatch, N, panel):
+    """Panels of 2 / 4 block columns with one rank-128 / rank-256 trailing update (syrk_panel_kernel, 128 x 128 tiles) and
+    look-ahead on a second stream: the factor reproduces K and equals the rank-64 factorisation to rounding (the path is the
+    default from 128 block columns on; test_C5_* in test_gpu_configs.py run it at N = 10000)."""
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    X, y, h = make_problem(N, 6, 50 + N)
+    o = OracleGP(6, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"])
+    K = o.get_matrix(X)
+    facs = {}
+    for tag, env, la in (("panel", panel, "1"), ("panel-serial", panel, "0"), ("rank64", "0", "1")):
+        if env is None:
+            monkeypatch.delenv("ALABI_CHOL_PANEL", raising=False)
+        else:
+            monkeypatch.setenv("ALABI_CHOL_PANEL", env)
+        monkeypatch.setenv("ALABI_CHOL_LOOKAHEAD", la)
+        g = HipGP(6, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+        L = g.solver.get_factor().cpu().numpy()
+        assert np.allclose(np.triu(L, 1), 0.0)
+        assert np.max(np.abs(L @ L.T - K)) <= 1e-12 * np.max(np.abs(K)), tag
+        facs[tag] = (L, g.log_likelihood(y), g.predict(y, X[:64] + 0.01, return_var=True))
+    assert np.array_equal(facs["panel"][0], facs["panel-serial"][0])             # the look-ahead changes no bit
+    assert np.max(np.abs(facs["panel"][0] - facs["rank64"][0])) <= 1e-9 * np.max(np.abs(facs["rank64"][0]))
+    assert abs(facs["panel"][1] - o.compute(X).log_likelihood(y)) <= 1e-9 * abs(facs["rank64"][1])
+    assert np.max(np.abs(facs["panel"][2][1] - facs["rank64"][2][1])) <= 1e-8 * np.exp(h["log_amp"])
