@@ -474,7 +474,18 @@ int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* 
             if (G > (W + 1) / 2) G = (W + 1) / 2;
             e->stream_grid = G;
             const size_t hist_words = ((size_t)e->chunk_cap + 1) * WT * (d + 2);   // row = coords, logp, accepted
-            if (err == hipSuccess) err = hipMalloc(&e->hist, hist_words * sizeof(unsigned long long));
+            if (err == hipSuccess) {
+                // the version history is the hand-off medium of the persistent kernels: fine-grained device memory shortens a
+                // cross-CU hop by ~15 % in the ping-pong micro-benchmark (tools/micro/pingpong); ALABI_ENS_HIST_FINE=0: plain
+                const char* fg = getenv("ALABI_ENS_HIST_FINE");
+                if (fg && fg[0] == '1') {
+                    err = hipExtMallocWithFlags(reinterpret_cast<void**>(&e->hist), hist_words * sizeof(unsigned long long),
+                                                hipDeviceMallocFinegrained);
+                    if (err != hipSuccess) { (void)hipGetLastError(); err = hipMalloc(&e->hist, hist_words * sizeof(unsigned long long)); }
+                } else {
+                    err = hipMalloc(&e->hist, hist_words * sizeof(unsigned long long));
+                }
+            }
             if (err == hipSuccess) err = hipMalloc(&e->err, sizeof(int));
             e->stream_ok = (err == hipSuccess) ? 1 : 0;
             e->spec_ok = (e->stream_ok && (long long)W * n_ensembles <= n_cu) ? 1 : 0;
@@ -495,6 +506,7 @@ int alabi_ens_destroy(alabi_ens* e) {
     if (e->run_state) (void)hipFree(e->run_state);
     if (e->consts) (void)hipFree(e->consts);
     if (e->hist) (void)hipFree(e->hist);
+    if (e->prop) (void)hipFree(e->prop);
     if (e->err) (void)hipFree(e->err);
     delete e;
     return ALABI_OK;

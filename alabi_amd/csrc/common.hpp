@@ -138,6 +138,7 @@ struct alabi_ens {
     long long* run_state = nullptr;  // device [4]: [0] first global step of the chunk, [1] steps done before it
     // persistent dataflow path (ens_stream_kernel)
     unsigned long long* hist = nullptr;  // [(chunk_cap+1)][E*W][d+1] version history of every walker
+    unsigned long long* prop = nullptr;  // [(chunk_cap+1)][E*W][d] proposals published by ens_spec_kernel (allocated on first use)
     int* err = nullptr;                  // [1] spin time-out flag
     int stream_grid = 0;                 // workgroups per ensemble of the persistent kernel
     int last_path = 0;                   // 1 persistent kernel, 2 its speculative variant, 0 one launch per half step

@@ -533,6 +533,7 @@ struct StreamArgs {
     const long long* run_state;
     int K, W, n0, d, Npad, thin_by, spin_limit, has_prior;
     long long* dbg;              // nullable: per-workgroup counters of ens_spec_kernel (ALABI_SPEC_DBG=1)
+    unsigned long long* prop;    // nullable: [(K+1)][E*W][d] published proposals of ens_spec_kernel (sentinel-filled like hist)
     double amp, mean, prior_const;
     KernelFn kf;
 };
@@ -859,7 +860,7 @@ ens_spec_kernel(StreamArgs p) {
         pend = record_load(2);
     }
     __syncthreads();
-    int rnd = 0;                                          // rounds so far: parity selects the LDS buffers
+    int rnd = 0;                                          // rounds so far: parity selects the LDS proposal buffer
     if (!comm) {
         // ---- compute and record waves: serve rounds until the kernel ends
         for (int t = 0; t < p.K; ++t) {
@@ -873,7 +874,9 @@ ens_spec_kernel(StreamArgs p) {
                 double qraw[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) qraw[k] = qs_s[par][k];
-                const int cin = __builtin_amdgcn_readfirstlane(__double2hiint(qs_s[par][63])) != 0;
+                // qs_s[par][63]: 0 = proposal outside the box (no sum), 1 + slot = sum slot the partials go to
+                const int tagw = __builtin_amdgcn_readfirstlane(__double2hiint(qs_s[par][63]));
+                const int cin = tagw != 0, slot = (tagw >> 30) & 1;   // high word of 1.0 = 0x3FF00000, of 2.0 = 0x40000000: bit 30
                 if (compute && cin) {
                     double q[D];
 #pragma unroll
@@ -895,12 +898,21 @@ ens_spec_kernel(StreamArgs p) {
                         if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                     }
                     const double wsum = wave_sum_dpp(acc);
-                    if (lane == 63) scratch[par][wv - 1] = wsum;
+                    if (lane == 63) scratch[slot][wv - 1] = wsum;
                 }
-                if (service && !fetched) {                 // once per item: ring slot t+2, issue t+3
-                    if (lane < 4) rec_s[(t + 2) & 3][lane] = pend;
-                    pend = record_load(t + 3);
-                    fetched = true;
+                if (service) {
+                    // publish the proposal of this round: a partner waiting for this walker's decision can already evaluate
+                    // "accepted" (p.prop == nullptr: no publishing).  Later rounds of the item overwrite it.
+                    if (p.prop && lane < p.d) {
+                        const int w_pub = (int)(unsigned)(rec_s[t & 3][0] & 0xffffffffull);
+                        st_sc1(p.prop + ((size_t)(t + 1) * WT + w_pub) * p.d + lane,
+                               (unsigned long long)__double_as_longlong(qs_s[par][32 + lane]));
+                    }
+                    if (!fetched) {                        // once per item: ring slot t+2, issue t+3
+                        if (lane < 4) rec_s[(t + 2) & 3][lane] = pend;
+                        pend = record_load(t + 3);
+                        fetched = true;
+                    }
                 }
                 __syncthreads();                           // barrier B: the partial sums are in LDS
             }
@@ -909,8 +921,12 @@ ens_spec_kernel(StreamArgs p) {
     }
     // ---- wave 0: the dependency chain.  Lanes 0..31 watch the walker's own row, lanes 32..63 the partner's row
     // (word hl of the row in lane hl: coordinates, logp, acceptance flag), so ONE load instruction looks at both.
+    // Sums are memoised in two slots, each tagged with the coordinates it was computed from; the accept test takes the slot
+    // whose tag equals the REAL rows, whatever those turn out to be.  Slot 0: the best rows known (real, else the previous
+    // version: right whenever the pending update is rejected); slot 1: the partner's PUBLISHED proposal in place of its row
+    // (right whenever its pending update is accepted).
     const int hl = lane & 31, grp = lane >> 5;
-    const bool need = hl <= p.d + 1;
+    const bool need = hl <= p.d + 1, isc = hl < p.d;       // words watched; coordinate words (what a sum depends on)
     const int wl = need ? hl : 0;                          // spare lanes re-read word 0 (keeps every lane's address valid)
     const double il_r = consts_s[0][lane], lo_r = consts_s[1][lane], hi_r = consts_s[2][lane];
     for (int t = 0; t < p.K; ++t) {
@@ -919,17 +935,20 @@ ens_spec_kernel(StreamArgs p) {
         const int w = (int)(unsigned)(ids & 0xffffffffull), cw = (int)(unsigned)(ids >> 32);
         const double zz = __longlong_as_double((long long)rs[1]);
         const double lnfac = __longlong_as_double((long long)rs[2]), lnu = __longlong_as_double((long long)rs[3]);
-        // own row: version t; partner row: version t (+1 when its half went first)
-        const unsigned long long* pa = p.hist + ((size_t)(t + (grp ? split : 0)) * WT + (grp ? cw : w)) * row + wl;
-        const bool has_prev = grp ? (t + split > 0) : (t > 0);             // is there a previous version to stand in?
+        const int vrow = t + (grp ? split : 0);            // own row: version t; partner row: version t (+1: its half went first)
+        const unsigned long long* pa = p.hist + ((size_t)vrow * WT + (grp ? cw : w)) * row + wl;
+        const bool has_prev = vrow > 0;                    // is there a previous version to stand in?
         const unsigned long long* pb = has_prev ? pa - (size_t)WT * row : pa;
-        unsigned long long real = ALABI_HIST_EMPTY, prev = ALABI_HIST_EMPTY;
+        // the partner's published proposal for the update that produces version vrow (partner lanes, coordinate words)
+        const bool use_prop = p.prop != nullptr && grp == 1 && isc && has_prev;
+        const unsigned long long* pp = use_prop ? p.prop + ((size_t)vrow * WT + cw) * p.d + hl : pa;
+        unsigned long long real = ALABI_HIST_EMPTY, prev = ALABI_HIST_EMPTY, prop = ALABI_HIST_EMPTY;
         bool own_real = false, par_real = false;
-        bool have_sum = false, used_own_real = false, used_par_real = false;
-        int sum_par = 0, all_in = 0, spins = 0;
-        double qv = 0.0;
+        unsigned long long tag0 = ALABI_HIST_EMPTY, tag1 = ALABI_HIST_EMPTY;   // rows the two slots were computed from
+        bool val0 = false, val1 = false;
+        int in0 = 0, in1 = 0, spins = 0;
+        double q0v = 0.0, q1v = 0.0;                       // lane k < d: coordinate k of the slot's proposal
         int n_rounds = 0, n_spec_rounds = 0, last_spec = 0;
-        // one look at the real rows: merge what has arrived (rows are immutable once written)
 #ifdef ALABI_SPEC_PROF
         long long t_det_own = 0, t_det_par = 0, t_round = 0;
         const long long t_item0 = __builtin_amdgcn_s_memrealtime();
@@ -947,48 +966,35 @@ ens_spec_kernel(StreamArgs p) {
             if (par_real && !p_) t_det_par = __builtin_amdgcn_s_memrealtime();
 #endif
         };
+        // does a slot's tag equal the rows `rows` on every coordinate word of both groups?
+        auto same = [&](unsigned long long tag, unsigned long long rows) { return __ballot(isc && tag != rows) == 0ull; };
         merge(ld_sc1(pa));
+        int fin = -1;                                      // slot that holds the sum of the real proposal
         for (;;) {
-            if (have_sum) {
-                // a guess is confirmed by "not accepted" in the real row (then the row IS the stand-in), refuted otherwise
-                if (!used_own_real && own_real) {
-                    if (__builtin_amdgcn_readlane((int)(unsigned)real, p.d + 1) == 0) used_own_real = true; else have_sum = false;
-                }
-                if (have_sum && !used_par_real && par_real) {
-                    if (__builtin_amdgcn_readlane((int)(unsigned)real, 32 + p.d + 1) == 0) used_par_real = true; else have_sum = false;
-                }
-                if (have_sum && used_own_real && used_par_real) break;      // the sum belongs to the real proposal: finish
+            // (1) everything known: take the matching slot, or compute it now
+            if (own_real && par_real) {
+                if (val0 && same(tag0, real)) { fin = 0; break; }
+                if (val1 && same(tag1, real)) { fin = 1; break; }
             }
-            bool go = false;
-            if (!have_sum) {
-                const bool grp_real = grp ? par_real : own_real;
-                if (!grp_real && has_prev && prev == ALABI_HIST_EMPTY) prev = ld_sc1(pb);
-                const unsigned long long miss = __ballot(need && !grp_real && (!has_prev || prev == ALABI_HIST_EMPTY));
-                go = miss == 0ull;
-            }
-            if (!go) {
-                // nothing to compute: watch the missing rows with two loads in flight (a look every half round trip)
-                // (relaxed agent-scope loads: the compiler keeps both in flight and waits with vmcnt(1), checked in the ISA)
-#ifdef ALABI_SPEC_PIPELINED_POLL
-                unsigned long long r1 = ld_sc1(pa), r2;
-                for (;;) {
-                    r2 = ld_sc1(pa);
-                    const bool o0 = own_real, p0 = par_real;
-                    merge(r1);
-                    if (own_real != o0 || par_real != p0) break;
-                    r1 = ld_sc1(pa);
-                    merge(r2);
-                    if (own_real != o0 || par_real != p0) break;
-                    if (!have_sum) break;                  // waiting for a stand-in: back to the outer loop to re-read it
-                    if ((spins += 2) > p.spin_limit ||
-                        ((spins & 62) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        spins = p.spin_limit;              // leave: the check below aborts
-                        break;
-                    }
+            // (2) targets, in order of likelihood: [best rows], then [partner replaced by its published proposal]
+            const bool grp_real = grp ? par_real : own_real;
+            if (!grp_real && has_prev && prev == ALABI_HIST_EMPTY) prev = ld_sc1(pb);
+            const unsigned long long best = grp_real ? real : prev;
+            const bool best_av = __ballot(need && !grp_real && (!has_prev || prev == ALABI_HIST_EMPTY)) == 0ull;
+            int target = -1;                               // 0: best rows -> slot 0; 1: proposal hypothesis -> slot 1
+            unsigned long long rows = best;
+            if (best_av && !(val0 && same(tag0, best)) && !(val1 && same(tag1, best))) target = 0;
+            if (target < 0 && best_av && !par_real && p.prop != nullptr) {
+                if (use_prop) prop = ld_sc1(pp);
+                const bool prop_av = __ballot(use_prop && prop == ALABI_HIST_EMPTY) == 0ull && (t + split > 0);
+                if (prop_av) {
+                    rows = use_prop ? prop : best;         // partner coordinates from the proposal, own rows as in `best`
+                    if (!same(best, rows) && !(val1 && same(tag1, rows)) && !(val0 && same(tag0, rows))) target = 1;
                 }
-#else
+            }
+            if (target < 0) {
+                // nothing to compute: look at the missing real rows again
                 merge(ld_sc1(pa));
-#endif
                 if ((spins += 1) > p.spin_limit ||
                     ((spins & 63) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                     if (lane == 0) { ctl_s[0][1] = 1; __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -997,24 +1003,25 @@ ens_spec_kernel(StreamArgs p) {
                 }
                 continue;
             }
-            // a round: proposal from the best rows known, kernel sum by the compute waves
+            // (3) a round: proposal from `rows`, kernel sum by the compute waves into slot `target`
             const int par = rnd & 1;
-            used_own_real = own_real; used_par_real = par_real;
             ++n_rounds; last_spec = !(own_real && par_real); n_spec_rounds += last_spec;
-            const unsigned long long best = (grp ? par_real : own_real) ? real : prev;
-            const double sv = __longlong_as_double((long long)best);
+            const double sv = __longlong_as_double((long long)rows);
             const double cv = __shfl(sv, lane + 32, 64);   // lane k < 32: word k of the partner's row
             int inb = 1;
-            double qs = 0.0;
+            double qs = 0.0, qv = 0.0;
             if (lane < p.d) {
                 qv = cv - (cv - sv) * zz;
                 inb = (qv > lo_r) && (qv < hi_r);
                 qs = qv * il_r;
             }
-            all_in = __all(inb);
+            const int all_in = __all(inb);
             if (lane < D) qs_s[par][lane] = qs;
-            if (lane == 63) qs_s[par][63] = all_in ? 1.0 : 0.0;
+            if (lane < p.d) qs_s[par][32 + lane] = qv;     // unscaled: what the record wave publishes
+            if (lane == 63) qs_s[par][63] = all_in ? (target ? 2.0 : 1.0) : 0.0;
             if (lane == 0) ctl_s[par][0] = 0;
+            if (target == 0) { tag0 = rows; q0v = qv; in0 = all_in; val0 = true; }
+            else { tag1 = rows; q1v = qv; in1 = all_in; val1 = true; }
 #ifdef ALABI_SPEC_PROF
             const long long tr0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1025,15 +1032,16 @@ ens_spec_kernel(StreamArgs p) {
 #ifdef ALABI_SPEC_PROF
             t_round += __builtin_amdgcn_s_memrealtime() - tr0;
 #endif
-            have_sum = true; sum_par = par;
         }
         // accept test on the sum of the real proposal, publish the new row, close the item for the other waves
         {
             const double sv = __longlong_as_double((long long)real);        // lanes < 32: the own row (lane d: its logp)
+            const double qv = fin ? q1v : q0v;
+            const int all_in = fin ? in1 : in0;
             double prior_q = 0.0;
             if (p.has_prior) prior_q = normal_prior_sum(consts_s[3], consts_s[4], lane, p.d, qv) + p.prior_const;
             double lp_new = -INFINITY;
-            if (all_in) lp_new = fma(p.amp, wave_partials_tree(scratch[sum_par], nwc), p.mean) + prior_q;
+            if (all_in) lp_new = fma(p.amp, wave_partials_tree(scratch[fin], nwc), p.mean) + prior_q;
             const double lp_old = lane_bcast(sv, p.d);
             const int acc_flag = (lnfac + lp_new - lp_old > lnu) ? 1 : 0;
             const double outv = (lane < p.d) ? (acc_flag ? qv : sv) : (acc_flag ? lp_new : lp_old);
@@ -1050,11 +1058,8 @@ ens_spec_kernel(StreamArgs p) {
             ++rnd;
             if (p.dbg && lane == 0) {                      // [0] items [1] rounds [2] guessed rounds [3] items finished on a guess [4] polls
                 long long* c = p.dbg + 16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
-                c[0] += 1; c[1] += n_rounds; c[2] += n_spec_rounds; c[3] += last_spec; c[4] += spins;
+                c[0] += 1; c[1] += n_rounds; c[2] += n_spec_rounds; c[3] += last_spec; c[4] += spins; c[12] += fin;
 #ifdef ALABI_SPEC_PROF
-                // units: 10 ns (s_memrealtime, 100 MHz).  [5] sum detect - publish of the row that arrived last, [6] samples;
-                // [7] store - last detection (items finished on a guess), [8] the same for the others, [9] time in rounds,
-                // [10] item time, [11] how often the partner's row was the last to arrive
                 const long long ts_o = t > 0 ? (long long)ld_sc1(tsb + (size_t)t * WT + w) : 0;
                 const long long ts_p = t + split > 0 ? (long long)ld_sc1(tsb + (size_t)(t + split) * WT + cw) : 0;
                 const bool par_last = t_det_par >= t_det_own;
@@ -1174,9 +1179,23 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
     const char* spec_env = getenv("ALABI_ENS_SPEC");
     // Opt-in (ALABI_ENS_SPEC=1): measured on MI355X at the headline size it is bit-identical but not faster than
     // ens_stream_kernel (2.09 vs 1.99 us per half step: 40 % of the proposals finish on a guess, the publish -> detect
-    // hand-off of 1.09 us stays on the chain either way).
+    // hand-off of 1.09 us stays on the chain either way; with published proposals as a second hypothesis
+    // (ALABI_ENS_SPEC_PROP=1) 59 % finish on a guess but the extra rounds keep wave 0 at barrier B: 2.45 us; DESIGN.md
+    // section 4).
     const bool spec = e->spec_ok && spec_env && spec_env[0] == '1';
     e->last_path = spec ? 2 : 1;
+    if (spec && !e->prop && e->d <= 30 && getenv("ALABI_ENS_SPEC_PROP") && getenv("ALABI_ENS_SPEC_PROP")[0] == '1') {
+        if (hipMalloc(&e->prop, ((size_t)e->chunk_cap + 1) * WT * e->d * sizeof(unsigned long long)) != hipSuccess) {
+            (void)hipGetLastError(); e->prop = nullptr;
+        }
+    }
+    if (spec && e->prop) {
+        const char* pe_ = getenv("ALABI_ENS_SPEC_PROP");   // second hypothesis (published proposals): measured slower, opt-in
+        if (pe_ && pe_[0] == '1' && e->d <= 30) {
+            a.prop = e->prop;
+            hipLaunchKernelGGL(ens_hist_fill_kernel, dim3(1024), dim3(256), 0, s, e->prop, (size_t)(K + 1) * WT * e->d);
+        }
+    }
     static long long* dbg_buf = nullptr;
     const char* dbg_env = getenv("ALABI_SPEC_DBG");
     if (spec && dbg_env && dbg_env[0] == '1') {
@@ -1200,8 +1219,8 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
         std::vector<long long> h(16 * (size_t)e->W * e->E);
         (void)hipMemcpyAsync(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
-        long long tot[12] = {0}, s0[2] = {0, 0}, s1[2] = {0, 0};
-        for (size_t i = 0; i < h.size(); i += 16) for (int k = 0; k < 12; ++k) tot[k] += h[i + k];
+        long long tot[12] = {0}, s0[2] = {0, 0}, s1[2] = {0, 0}, h_prop_fin = 0;
+        for (size_t i = 0; i < h.size(); i += 16) { for (int k = 0; k < 12; ++k) tot[k] += h[i + k]; h_prop_fin += h[i + 12]; }
         for (int g = 0; g < e->W; ++g) { long long* t2 = g < n0 ? s0 : s1; t2[0] += h[16 * g + 3]; t2[1] += h[16 * g]; }
         if (tot[6] > 0)
             fprintf(stderr, "[ens_spec_kernel prof] publish->detect of the last row %.3f us (%lld samples, partner last %.2f); last detection->store: "
@@ -1212,6 +1231,7 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
                         "(set 0: %.3f, set 1: %.3f) polls/item %.2f\n", K, tot[0], (double)tot[1] / tot[0], (double)tot[2] / tot[0],
                 (double)tot[3] / tot[0], s0[1] ? (double)s0[0] / s0[1] : 0.0, s1[1] ? (double)s1[0] / s1[1] : 0.0,
                 (double)tot[4] / tot[0]);
+        fprintf(stderr, "[ens_spec_kernel] finished on the proposal slot: %.3f of the items\n", (double)h_prop_fin / tot[0]);
     }
     hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp,
                        e->hist + (size_t)K * WT * row, WT, e->d, 0);

@@ -372,7 +372,7 @@ def main():
         # MI355X_MICROARCH.md section HBM).  A PMC pass cannot run inside this process, so the number is read from
         # profiles/ and is null when the file is absent or the workload differs from the profiled one.
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_by_kernel.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_by_kernel.json")
         if os.path.exists(pmc_path) and args.config == "C3" and args.ensembles == 1 and not shard:
             try:
                 allk = json.load(open(pmc_path))

@@ -215,19 +215,22 @@ def test_speculative_kernel_equals_the_other_paths(setup, monkeypatch):
     for W, E, nsteps, thin in ((256, 1, 1500, 1), (64, 4, 400, 3), (37, 2, 257, 1), (10, 1, 1100, 1)):
         p0 = np.random.RandomState(W + E).uniform(-2.5, 2.5, (W * E, 5))
         runs = {}
-        for tag, stream, spec in (("spec", "1", "1"), ("stream", "1", "0"), ("half", "0", "0")):
+        for tag, stream, spec in (("spec", "1", "1"), ("spec+prop", "1", "1"), ("stream", "1", "0"), ("half", "0", "0")):
             monkeypatch.setenv("ALABI_ENS_STREAM", stream)
             monkeypatch.setenv("ALABI_ENS_SPEC", spec)
+            monkeypatch.setenv("ALABI_ENS_SPEC_PROP", "1" if tag == "spec+prop" else "0")
             s = EnsembleSampler(W, 5, g, y, bounds, seed=17, n_ensembles=E)
             s.run_mcmc(p0, nsteps, thin_by=thin)
             assert getattr(s, "stream_fallbacks", 0) == 0
-            assert s.last_stream_kernel == {"spec": "ens_spec_kernel", "stream": "ens_stream_kernel", "half": None}[tag]
+            assert s.last_stream_kernel == {"spec": "ens_spec_kernel", "spec+prop": "ens_spec_kernel",
+                                            "stream": "ens_stream_kernel", "half": None}[tag]
             runs[tag] = (s.get_chain(), s.get_log_prob(), s._naccept.cpu().numpy().copy())
-        for tag in ("stream", "half"):
+        for tag in ("spec+prop", "stream", "half"):
             assert np.array_equal(runs["spec"][0], runs[tag][0]), (W, E, tag)
             assert np.array_equal(runs["spec"][1], runs[tag][1])
             assert np.array_equal(runs["spec"][2], runs[tag][2])
     monkeypatch.delenv("ALABI_ENS_SPEC")
+    monkeypatch.delenv("ALABI_ENS_SPEC_PROP")
 
 
 def test_persistent_kernel_timeout_falls_back(monkeypatch):
