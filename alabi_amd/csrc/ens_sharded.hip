@@ -115,7 +115,7 @@ shard_nacc_kernel(const long long* __restrict__ all, int nranks, int W, long lon
 }
 
 static int all_gather(alabi_comm* c, const double* send, double* recv, size_t count, hipStream_t s) {
-    if (c->nranks == 1) {
+    if (c->nranks == 1 && !c->nccl) {
         ALABI_HIP_CHECK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
         return ALABI_OK;
     }
@@ -145,7 +145,7 @@ int alabi_dist_comm_create(const void* id, int rank, int nranks, alabi_comm** ou
     alabi_comm* c = new (std::nothrow) alabi_comm();
     if (!c) return ALABI_BAD_ARGUMENT;
     c->rank = rank; c->nranks = nranks;
-    if (nranks > 1) {
+    if (nranks > 1 || id) {                      // an id with ONE rank: a real one-rank RCCL communicator (rehearsal on a one-GPU box)
         if (!rccl().ok) { delete c; g_last_error = "librccl.so could not be loaded"; return ALABI_HIP_ERROR; }
         ncclUniqueId uid;
         memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
@@ -215,7 +215,7 @@ int alabi_ens_run_sharded(alabi_ens* e, alabi_comm* c, double* coords, double* l
                 int b, en;
                 slice_bounds(nS, c->nranks, c->rank, &b, &en);
                 if (en > b && (st = alabi_ens_half_step(e, coords, logp, t, split, b, en, c->nacc_local, stream)) != ALABI_OK) return st;
-                if (c->nranks > 1) {
+                if (c->nranks > 1 || c->nccl) {
                     const int* list = order + (split ? n0 : 0);
                     if (en > b)
                         hipLaunchKernelGGL(shard_pack_kernel, dim3(((en - b) * row + 255) / 256), dim3(256), 0, s, list, b, en, d, coords,

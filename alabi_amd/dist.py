@@ -19,6 +19,7 @@ oracle-backed stand-in with the same four methods to check the partition / gathe
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -174,6 +175,10 @@ class ShardedRun:
                                                            C.byref(comm)), "alabi_dist_comm_create_callback")
         else:
             uid = None
+            if self.world == 1 and os.environ.get("ALABI_DIST_FORCE_RCCL") == "1":   # one-rank RCCL communicator (rehearsal)
+                buf = C.create_string_buffer(128)
+                _lib.check(lib.alabi_dist_unique_id(buf), "alabi_dist_unique_id")
+                uid = buf
             if self.world > 1:
                 box = [None]
                 if self.rank == 0:

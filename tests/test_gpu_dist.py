@@ -71,8 +71,9 @@ def test_two_ranks_match_single_process_hip_chain():
         assert np.array_equal(n_r, ref._naccept.cpu().numpy())
 
 
-def test_sharded_run_single_rank_and_rccl_loads():
-    """nranks == 1 through the C loop equals the plain run; librccl.so resolves (ncclGetUniqueId returns 128 bytes)."""
+def test_sharded_run_single_rank_and_rccl_loads(monkeypatch):
+    """nranks == 1 through the C loop equals the plain run, with the memcpy stand-in and with a REAL one-rank RCCL
+    communicator (ncclCommInitRank + one ncclAllGather per half step on the stream); librccl.so resolves."""
     import ctypes as C
     import torch
     from conftest import make_problem
@@ -88,6 +89,13 @@ def test_sharded_run_single_rank_and_rccl_loads():
     chain, coords, logp, nacc = ShardedRun(s).run(torch.as_tensor(p0, device="cuda"), nsteps, thin_by=3)
     assert np.array_equal(chain.cpu().numpy(), ref.get_chain())
     assert np.array_equal(nacc.cpu().numpy(), ref._naccept.cpu().numpy())
+    monkeypatch.setenv("ALABI_DIST_FORCE_RCCL", "1")
+    s2 = EnsembleSampler(W, 4, gp, y, bounds, seed=77)
+    run2 = ShardedRun(s2)
+    chain2, _, _, nacc2 = run2.run(torch.as_tensor(p0, device="cuda"), nsteps, thin_by=3)
+    torch.cuda.synchronize()
+    assert np.array_equal(chain2.cpu().numpy(), ref.get_chain()) and np.array_equal(nacc2.cpu().numpy(), nacc.cpu().numpy())
+    del run2
     buf = C.create_string_buffer(128)
     _lib.check(_lib.lib().alabi_dist_unique_id(buf), "alabi_dist_unique_id")
     assert any(b != 0 for b in buf.raw)
