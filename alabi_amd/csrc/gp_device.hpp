@@ -83,6 +83,26 @@ __device__ inline double exp_direct(double x) {
     return ldexp(p, (int)n);
 }
 
+// exp(x), x <= ~0, with a 32-entry table of 2^(j/32) in LDS (`tab`, filled by the caller: tab[j] = exp2(j / 32.0)):
+// x = (32 n + j) ln2/32 + r, |r| <= ln2/64, degree-6 Taylor polynomial (truncation 3e-18), result 2^n tab[j] p(r).
+// 13 instructions on the fp64 pipe instead of 19, plus 3 integer instructions and one LDS read -- pays where the pipe is the
+// bound (several waves per SIMD), not in the one-wave-per-SIMD ensemble kernels (tools/micro/ksum_bench: -1 %).
+__device__ inline double exp_tab32(double x, const double* tab) {
+    const double k = rint(x * 46.16624130844683);                 // 32 / ln2
+    double r = fma(k, -0x1.62e42fee00000p-6, x);                   // ln2 / 32, high part (exact product for |k| < 2^20)
+    r = fma(k, -0x1.a39ef35793c76p-38, r);                         // low part
+    const int ki = (int)k;
+    const double t = tab[ki & 31];
+    double p = 0.001388888888888889;                               // 1/6!
+    p = fma(p, r, 0.008333333333333333);
+    p = fma(p, r, 0.041666666666666664);
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p * t, ki >> 5);
+}
+
 // GENERIC = false compiles the squared-exponential alone (no run-time switch in the hot loops).
 template <bool GENERIC = true>
 __device__ inline double radial(double r2, KernelFn kf) {

@@ -57,7 +57,9 @@ predict_mean_tile_kernel(const double* __restrict__ Xt, const double* __restrict
     __shared__ double xt[D][256];
     __shared__ double al[256];
     __shared__ double part[4][64];
+    __shared__ double etab[32];                                  // 2^(j/32) for exp_tab32 (first barrier of the loop orders it)
     const int tid = threadIdx.x, c = tid & 63, w = tid >> 6;
+    if (tid < 32) etab[tid] = exp2((double)tid * 0.03125);
     const long long m = (long long)blockIdx.x * 64 + c;
     double q[D];
 #pragma unroll
@@ -83,7 +85,7 @@ predict_mean_tile_kernel(const double* __restrict__ Xt, const double* __restrict
                 double df = xt[k][nn] - q[k];
                 r2 = fma(df, df, r2);
             }
-            acc = fma(al[nn], radial<GENERIC>(r2, kf), acc);
+            acc = fma(al[nn], GENERIC ? radial<true>(r2, kf) : exp_tab32(-0.5 * r2, etab), acc);
         }
     }
     part[w][c] = acc;
@@ -891,6 +893,9 @@ __global__ void __launch_bounds__(256)
 predict_mean_mfma_kernel(const double* __restrict__ Xa, const double* __restrict__ alpha, int Npad,
                          const double* __restrict__ Xs, int d, long long M, DimVec inv_len, double amp, double mean,
                          KernelFn kf, double* __restrict__ mu) {
+    __shared__ double etab[32];                                  // 2^(j/32) for exp_tab32
+    if (threadIdx.x < 32) etab[threadIdx.x] = exp2((double)threadIdx.x * 0.03125);
+    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     const long long q0 = ((long long)blockIdx.x * 4 + wv) * 64;
@@ -932,7 +937,7 @@ predict_mean_mfma_kernel(const double* __restrict__ Xa, const double* __restrict
             for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qt][s], b[s], acc, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                 // C/D layout: row (query) lk + 4 i, column (point) lr
-                const double f = GENERIC ? radial<true>(fmax(-2.0 * acc[i], 0.0), kf) : exp_direct(acc[i]);
+                const double f = GENERIC ? radial<true>(fmax(-2.0 * acc[i], 0.0), kf) : exp_tab32(acc[i], etab);
                 sum[qt][i] = fma(al, f, sum[qt][i]);
             }
         }

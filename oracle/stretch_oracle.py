@@ -18,7 +18,7 @@ Two statements of the same step are given:
   (order / u_z / partner / u_acc), which is the contract of the HIP half-step
   kernel (include/alabi_hip.h: alabi_ens_step_with_randoms).  Given the draws
   recorded from the literal step it must reproduce it bit for bit
-  (tests/test_oracle_stretch.py), which is what "walker index arithmetic
+  (tests/test_oracle_crosscheck.py::test_array_step_reproduces_emcee_literal_step_bit_for_bit), which is what "walker index arithmetic
   bit-exact given the same uniforms" means in this repo.
 
 ``draw_step_randoms`` is the counter-based generator (Philox4x32-10) the device
