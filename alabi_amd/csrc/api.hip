@@ -1,4 +1,5 @@
 // extern "C" entry points of libalabi_hip.so (declared in include/alabi_hip.h).
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
@@ -141,6 +142,7 @@ int alabi_gp_destroy(alabi_gp* gp) {
     if (gp->flags) (void)hipFree(gp->flags);
     if (gp->red) (void)hipFree(gp->red);
     if (gp->info) (void)hipFree(gp->info);
+    if (gp->chol_ctl) (void)hipFree(gp->chol_ctl);
     if (gp->ws || gp->winv) (void)hipDeviceSynchronize();   // nothing in flight may still use the buffers handed to the cache
     alabi::dev_cache_give(gp->ws, gp->ws_bytes);
     if (gp->scan) (void)hipFree(gp->scan);
@@ -179,9 +181,25 @@ int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream) {
     int st;
     if ((st = launch_prepare_inputs(gp, X, N, s)) != ALABI_OK) return st;
     if ((st = launch_assemble(gp, s)) != ALABI_OK) return st;
-    if ((st = launch_cholesky(gp, s)) != ALABI_OK) return st;
+    // up to 64 block columns: the task-queue factorisation (one launch); a wait that runs out there is remembered for a while
+    static std::atomic<int> tasks_penalty{0};
+    int queued = 0;
+    if (tasks_penalty.load(std::memory_order_relaxed) > 0) tasks_penalty.fetch_sub(1, std::memory_order_relaxed);
+    else if ((st = launch_cholesky_tasks(gp, s, &queued)) != ALABI_OK) return st;
+    if (!queued && (st = launch_cholesky(gp, s)) != ALABI_OK) return st;
     int info = 0;
     ALABI_HIP_CHECK(hipMemcpyAsync(&info, gp->info, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (queued) {
+        int timed_out = 0;
+        ALABI_HIP_CHECK(hipMemcpyAsync(&timed_out, gp->chol_ctl + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+        ALABI_HIP_CHECK(hipStreamSynchronize(s));
+        if (timed_out) {                                   // undefined matrix state: assemble and factorise again, step by step
+            tasks_penalty.store(64, std::memory_order_relaxed);
+            if ((st = launch_assemble(gp, s)) != ALABI_OK) return st;
+            if ((st = launch_cholesky(gp, s)) != ALABI_OK) return st;
+            ALABI_HIP_CHECK(hipMemcpyAsync(&info, gp->info, sizeof(int), hipMemcpyDeviceToHost, s));
+        }
+    }
     ALABI_HIP_CHECK(hipStreamSynchronize(s));
     gp->last_pivot = info;
     if (info != 0) return ALABI_NOT_POSITIVE_DEFINITE;

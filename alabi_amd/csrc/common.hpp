@@ -75,6 +75,8 @@ struct alabi_gp {
     int* flags = nullptr;     // [1] time-out flag of the dataflow solve
     double* red = nullptr;    // [4] reductions (logdet, r.alpha)
     int* info = nullptr;      // [1] Cholesky info (0 ok, else 1-based pivot)
+    int* chol_ctl = nullptr;  // task-queue factorisation: [0] queue head, [1] time-out flag, [2 + i * nb + j] tile versions
+    size_t chol_ctl_ints = 0;
     double* ws = nullptr;     // predict-variance workspace
     size_t ws_bytes = 0;
     double* scan = nullptr;   // utility-scan scratch (partials)
@@ -154,6 +156,7 @@ int launch_kernel_matrix(const double* X1, int n1, const double* X2, int n2, int
                          const DimVec& inv_len, KernelFn kf, double* K, hipStream_t s);
 // gp_cholesky.hip
 int launch_cholesky(alabi_gp* gp, hipStream_t s);
+int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched);
 // gp_solve.hip
 int launch_alpha(alabi_gp* gp, hipStream_t s);
 int launch_reductions(alabi_gp* gp, hipStream_t s);

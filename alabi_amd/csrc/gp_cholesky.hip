@@ -16,6 +16,10 @@
 //                     slabs), so the diagonal factorisation costs no launch of its own.  A non-positive
 //                     pivot is reported as LAPACK's potrf `info` (1-based).
 // The matrix is [Npad, Npad] row-major with identity padding, so every block is full.
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
 #include "gp_device.hpp"
 
 namespace alabi {
@@ -407,10 +411,364 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
             }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Task-queue factorisation for up to 64 block columns (N <= 4096): ONE launch instead of 2 nb - 1.
+// The launch-per-step path above is a chain of dependent kernels: per block column a panel solve (11 us) and an update with
+// the next diagonal factorisation fused in (19.6 us), each behind a kernel boundary -- 1.02 ms at N = 2000 for 2.67 GFLOP.
+// Here the same 64 x 64 tile operations are TASKS in a static topological order; persistent workgroups draw the next task
+// index from one atomic counter, wait (bounded) until the tile versions it depends on have been published, run it and
+// publish its own tile version.  A workgroup only ever waits for tasks with a smaller index, and every drawn task is held by
+// a running workgroup, so the queue cannot deadlock even when not all workgroups are resident.  Hand-off between workgroups:
+// tiles are written with write-through (sc1) stores, every wave drains its stores, one barrier, then ONE lane publishes
+// the tile's version with an sc1 store; readers poll the version words and read the tiles with sc1 loads
+// (cdna_hip_programming.md Guideline 16, R1 with sc1 loads in place of the acquire).
+//   CHAIN(k)      k >= 1: solve tile (k, k-1) against L[k-1,k-1], publish it, apply it to tile (k, k) and factorise that
+//                 tile on the spot -- the whole critical path of a block column in ONE workgroup without leaving LDS;
+//                 CHAIN(0) factorises tile (0, 0).
+//   TRSM(i, k)    i >= k + 2: the other tiles of the panel.
+//   UPDATE(i,j,k) tile (i, j) -= tile (i, k) tile (j, k)^T for i >= j > k except (k+1, k+1).
+// Order per block column k: CHAIN(k+1) first, then the panel solves, then the updates of column k+1 (the next chain's
+// inputs), then the rest -- the chain never queues behind bulk updates.  ver[i][j] = number of steps applied to tile (i, j);
+// j + 1 means final.
+struct CholTask { int type, i, j, k; };
+
+__device__ inline void tile_load_sc1(double (*T)[66], const double* __restrict__ src, int ld, int tid) {
+#pragma unroll
+    for (int e_ = 0; e_ < 16; ++e_) {
+        const int e = tid + 256 * e_, r = e >> 6, c = e & 63;
+        T[r][c] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(src + (size_t)r * ld + c),
+                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+}
+__device__ inline void tile_store_sc1(double* __restrict__ dst, int ld, double (*T)[66], int tid, bool lower_only) {
+#pragma unroll
+    for (int e_ = 0; e_ < 16; ++e_) {
+        const int e = tid + 256 * e_, r = e >> 6, c = e & 63;
+        if (!lower_only || c <= r)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + (size_t)r * ld + c),
+                               (unsigned long long)__double_as_longlong(T[r][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// every wave has drained its stores and passed the barrier before ONE lane publishes the version
+__device__ inline void publish_version(int* ver, int value, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(ver, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// X L_kk^T = B for the 64 rows of `bs` (in place), L_kk in `lkk`, 1 / L_jj in `di`: the body of trsm_panel_kernel.
+__device__ inline void trsm_tile_lds(double (*lkk)[66], double (*bs)[66], const double* di, int tid) {
+    const int w = tid >> 6, lane = tid & 63;
+    const int row = 16 * w + (lane & 15);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c0 = 16 * s;
+        if (lane < 16) {
+            double b[16], dj[16], lreg[120];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { b[j] = bs[row][c0 + j]; dj[j] = di[c0 + j]; }
+            {
+                int q = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+#pragma unroll
+                    for (int k = j + 1; k < 16; ++k) lreg[q++] = lkk[c0 + k][c0 + j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                int q = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    b[j] *= dj[j];
+#pragma unroll
+                    for (int k = j + 1; k < 16; ++k) b[k] = fma(-b[j], lreg[q++], b[k]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bs[row][c0 + j] = b[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = s + 1; t < 4; ++t) tile_update_16<66>(bs, 16 * w, 16 * t, bs, 16 * w, lkk, 16 * t, c0, lane);
+        __syncthreads();
+    }
+}
+
+// Module-scope LDS, named directly by the non-inlined phase functions (as pointer arguments they would degrade to generic
+// pointers).  The panel solve and the diagonal factorisation are separate noinline functions: inlined into the task loop their
+// live ranges merge with the loop's and the serial recurrences fill up with AGPR moves (8.6 / 13.1 us instead of 5 / 9).
+__shared__ double ct_T0[64][66];
+__shared__ double ct_T1[64][66];
+__shared__ double ct_T2[64][66];                                      // CHAIN: the diagonal tile, parked while the panel tile is solved
+__shared__ double ct_di[64];
+__device__ __attribute__((noinline)) void ct_trsm() { trsm_tile_lds(ct_T0, ct_T1, ct_di, threadIdx.x); }
+__device__ __attribute__((noinline)) double ct_potrf(int kb, int* info) {
+    return potrf_tile_lds_wg<66>(ct_T0, threadIdx.x, __builtin_amdgcn_readfirstlane(kb), info);
+}
+// A tile in flight: all 16 loads of a thread are issued before the first one is consumed (several tiles are fetched
+// back to back and only then written to LDS: one memory round trip instead of one per tile)
+struct TileRegs { unsigned long long v[16]; };
+__device__ inline void tile_fetch(TileRegs& r, const double* __restrict__ src, int ld, int tid) {
+#pragma unroll
+    for (int e_ = 0; e_ < 16; ++e_) {
+        const int e = tid + 256 * e_;
+        r.v[e_] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src + (size_t)(e >> 6) * ld + (e & 63)), __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ inline void tile_put(double (*T)[66], const TileRegs& r, int tid) {
+#pragma unroll
+    for (int e_ = 0; e_ < 16; ++e_) {
+        const int e = tid + 256 * e_;
+        T[e >> 6][e & 63] = __longlong_as_double((long long)r.v[e_]);
+    }
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __restrict__ tasks, int ntasks, int* __restrict__ ctl,
+                  int* __restrict__ info, double* __restrict__ dinv, int spin_limit) {
+    double (*T0)[66] = ct_T0; double (*T1)[66] = ct_T1; double (*T2)[66] = ct_T2; double* di = ct_di;
+    __shared__ int task_s[5];
+    int* head = ctl; int* err = ctl + 1; int* ver = ctl + 2;          // ver[i * nb + j]
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+    for (;;) {
+        __syncthreads();                                              // the previous task is done with LDS and task_s
+        if (tid == 0) {
+            const int idx = atomicAdd(head, 1);
+            task_s[4] = idx;
+            if (idx < ntasks) { const CholTask t = tasks[idx]; task_s[0] = t.type; task_s[1] = t.i; task_s[2] = t.j; task_s[3] = t.k; }
+        }
+        __syncthreads();
+        if (task_s[4] >= ntasks) return;
+        const int type = task_s[0], ti = task_s[1], tj = task_s[2], tk = task_s[3];
+#ifdef ALABI_CHOL_PROF
+        const long long pw0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        // ---- dependencies: up to three (tile, version) pairs, polled by lanes 0..2 of wave 0
+        if (w == 0) {
+            int di_ = 0, dj_ = 0, need = 0;                           // lane 0 / 1 / 2
+            if (type == 0) {                                          // CHAIN(k): L[k-1,k-1] final, tile (k,k-1) and (k,k) at k-1
+                if (l == 0) { di_ = tk - 1; dj_ = tk - 1; need = tk; }
+                if (l == 1) { di_ = tk; dj_ = tk - 1; need = tk - 1; }
+                if (l == 2) { di_ = tk; dj_ = tk; need = tk - 1; }
+                if (tk == 0) need = 0;
+                if (tk == 0) { di_ = 0; dj_ = 0; }
+            } else if (type == 1) {                                   // TRSM(i,k): L[k,k] final, tile (i,k) at k
+                if (l == 0) { di_ = tk; dj_ = tk; need = tk + 1; }
+                if (l == 1) { di_ = ti; dj_ = tk; need = tk; }
+            } else {                                                  // UPDATE(i,j,k): (i,k), (j,k) final, tile (i,j) at k
+                if (l == 0) { di_ = ti; dj_ = tk; need = tk + 1; }
+                if (l == 1) { di_ = tj; dj_ = tk; need = tk + 1; }
+                if (l == 2) { di_ = ti; dj_ = tj; need = tk; }
+            }
+            const bool active = l < 3 && need > 0;
+            int spins = 0, ok = 1;
+            while (true) {
+                int have = need;
+                if (active) have = __hip_atomic_load(ver + di_ * nb + dj_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(have >= need)) break;
+                if (++spins > spin_limit || ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok && l == 0) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); task_s[4] = ntasks; }
+        }
+        __syncthreads();
+#ifdef ALABI_CHOL_PROF
+        if (tid == 0 && type == 0 && tk > 0) reinterpret_cast<long long*>(ctl + ((2 + nb * nb + 1) & ~1))[7] += __builtin_amdgcn_s_memrealtime() - pw0;
+#endif
+        if (task_s[4] >= ntasks) return;                              // a wait ran out: every workgroup leaves at its next check
+        if (type == 2) {
+            // ---------------- UPDATE(i, j, k)
+            TileRegs ra, rb;
+            tile_fetch(ra, A + (size_t)(ti * 64) * ld + tk * 64, ld, tid);
+            tile_fetch(rb, A + (size_t)(tj * 64) * ld + tk * 64, ld, tid);
+            double* C = A + (size_t)(ti * 64 + 16 * w) * ld + tj * 64;
+            v4f64 acc[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[n][i] = __longlong_as_double((long long)__hip_atomic_load(
+                        reinterpret_cast<const unsigned long long*>(C + (size_t)(lk + 4 * i) * ld + 16 * n + lr), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT));
+            tile_put(T0, ra, tid); tile_put(T1, rb, tid);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const double a = -T0[16 * w + lr][4 * ks + lk];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T1[16 * n + lr][4 * ks + lk], acc[n], 0, 0, 0);
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(C + (size_t)(lk + 4 * i) * ld + 16 * n + lr),
+                                       (unsigned long long)__double_as_longlong(acc[n][i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            publish_version(ver + ti * nb + tj, tk + 1, tid);
+        } else if (type == 1) {
+            // ---------------- TRSM(i, k)
+            TileRegs ra, rb;
+            tile_fetch(ra, A + (size_t)(tk * 64) * ld + tk * 64, ld, tid);
+            tile_fetch(rb, A + (size_t)(ti * 64) * ld + tk * 64, ld, tid);
+            if (tid < 64) di[tid] = __longlong_as_double((long long)__hip_atomic_load(
+                              reinterpret_cast<const unsigned long long*>(dinv + tk * 64 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            tile_put(T0, ra, tid); tile_put(T1, rb, tid);
+            __syncthreads();
+            ct_trsm();
+            tile_store_sc1(A + (size_t)(ti * 64) * ld + tk * 64, ld, T1, tid, false);
+            publish_version(ver + ti * nb + tk, tk + 1, tid);
+        } else {
+            // ---------------- CHAIN(k)
+            double* D = A + (size_t)(tk * 64) * ld + tk * 64;
+#ifdef ALABI_CHOL_PROF
+            long long* prof = reinterpret_cast<long long*>(ctl + ((2 + nb * nb + 1) & ~1));
+            const long long p0 = __builtin_amdgcn_s_memrealtime();
+            long long p1 = p0, p2 = p0, p3 = p0, p4 = p0;
+#endif
+            if (tk > 0) {
+                {
+                    TileRegs ra, rb, rc;
+                    tile_fetch(ra, A + (size_t)((tk - 1) * 64) * ld + (tk - 1) * 64, ld, tid);
+                    tile_fetch(rb, A + (size_t)(tk * 64) * ld + (tk - 1) * 64, ld, tid);
+                    tile_fetch(rc, D, ld, tid);
+                    if (tid < 64) di[tid] = __longlong_as_double((long long)__hip_atomic_load(
+                                      reinterpret_cast<const unsigned long long*>(dinv + (tk - 1) * 64 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    tile_put(T0, ra, tid); tile_put(T1, rb, tid); tile_put(T2, rc, tid);
+                }
+                __syncthreads();
+#ifdef ALABI_CHOL_PROF
+                p1 = __builtin_amdgcn_s_memrealtime();
+#endif
+                ct_trsm();
+#ifdef ALABI_CHOL_PROF
+                p2 = __builtin_amdgcn_s_memrealtime();
+#endif
+                tile_store_sc1(A + (size_t)(tk * 64) * ld + (tk - 1) * 64, ld, T1, tid, false);
+                publish_version(ver + tk * nb + (tk - 1), tk, tid);      // the solved panel tile is final: updates of column k can start
+#ifdef ALABI_CHOL_PROF
+                p3 = __builtin_amdgcn_s_memrealtime();
+#endif
+                v4f64 acc[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[n][i] = T2[16 * w + lk + 4 * i][16 * n + lr];
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const double a = -T1[16 * w + lr][4 * ks + lk];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T1[16 * n + lr][4 * ks + lk], acc[n], 0, 0, 0);
+                }
+                __syncthreads();                                      // everyone is done reading T0 (L[k-1,k-1])
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) T0[16 * w + lk + 4 * i][16 * n + lr] = acc[n][i];
+            } else {
+                tile_load_sc1(T0, D, ld, tid);
+            }
+            __syncthreads();
+#ifdef ALABI_CHOL_PROF
+            p4 = __builtin_amdgcn_s_memrealtime();
+#endif
+            const double rinv = ct_potrf(tk, info);
+#ifdef ALABI_CHOL_PROF
+            const long long p5 = __builtin_amdgcn_s_memrealtime();
+#endif
+            if (w == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dinv + tk * 64 + l),
+                                           (unsigned long long)__double_as_longlong(rinv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tile_store_sc1(D, ld, T0, tid, true);
+            publish_version(ver + tk * nb + tk, tk + 1, tid);
+#ifdef ALABI_CHOL_PROF
+            if (tid == 0 && tk > 0) {   // 10-ns units: [0] loads [1] trsm [2] store+publish panel [3] mfma+park [4] potrf [5] store+publish diag [6] count [7] wait for deps
+                const long long p6 = __builtin_amdgcn_s_memrealtime();
+                prof[0] += p1 - p0; prof[1] += p2 - p1; prof[2] += p3 - p2; prof[3] += p4 - p3; prof[4] += p5 - p4; prof[5] += p6 - p5; prof[6] += 1;
+            }
+#endif
+        }
+    }
+}
+
 static int tiles_in_cols(int ntr, int tc0, int tc1) {
     int n = 0;
     for (int tj = tc0; tj < tc1; ++tj) n += ntr - tj;
     return n;
+}
+
+// Task list of the queue kernel for nb block columns (built once per nb and kept on the device).
+static int chol_task_list(int nb, const CholTask** dev, int* count) {
+    static std::mutex mu;
+    static std::map<int, std::pair<CholTask*, int>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(nb);
+    if (it == cache.end()) {
+        std::vector<CholTask> t;
+        t.push_back({0, 0, 0, 0});
+        for (int k = 0; k + 1 < nb; ++k) {
+            t.push_back({0, k + 1, k + 1, k + 1});                                   // CHAIN(k+1): needs only CHAIN(k) and older updates
+            for (int i = k + 2; i < nb; ++i) t.push_back({1, i, k, k});               // the rest of panel k
+            for (int i = k + 2; i < nb; ++i) t.push_back({2, i, k + 1, k});           // column k+1 first: inputs of CHAIN(k+2) / panel k+1
+            for (int j = k + 2; j < nb; ++j)
+                for (int i = j; i < nb; ++i) t.push_back({2, i, j, k});
+        }
+        CholTask* d = nullptr;
+        ALABI_HIP_CHECK(hipMalloc(&d, t.size() * sizeof(CholTask)));
+        ALABI_HIP_CHECK(hipMemcpy(d, t.data(), t.size() * sizeof(CholTask), hipMemcpyHostToDevice));
+        it = cache.emplace(nb, std::make_pair(d, (int)t.size())).first;
+    }
+    *dev = it->second.first; *count = it->second.second;
+    return ALABI_OK;
+}
+
+// 1 when the queue kernel was launched (the caller reads gp->chol_ctl[1] after its synchronisation: non-zero = a wait ran out,
+// the matrix is in an undefined state and must be assembled and factorised again on the launch-per-step path).
+int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
+    *launched = 0;
+    const int ld = gp->Npad, nb = gp->Npad / 64;
+    // Opt-in (ALABI_CHOL_TASKS=1).  Measured at N = 2000 (tools/prof_cholesky.py, -DALABI_CHOL_PROF): 1.06 ms, the same as the
+    // launch-per-step path -- per block column the chain task spends 2.1 us fetching its three tiles, 8.6 us in the panel
+    // solve, 2.5 us in the diagonal update, 13.1 us in the 64-pivot factorisation and 2 us publishing: the two serial
+    // recurrences are 22 of its 28 us, the launch boundaries this design removes were only ~3 us per column.
+    const char* env = getenv("ALABI_CHOL_TASKS");
+    if (nb < 3 || nb > 64 || !(env && env[0] == '1')) return ALABI_OK;
+    const size_t ctl_ints = 2 + (size_t)nb * nb + 64;                  // + 64: phase timers of an ALABI_CHOL_PROF build
+    if (gp->chol_ctl_ints < ctl_ints) {
+        if (gp->chol_ctl) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); ALABI_HIP_CHECK(hipFree(gp->chol_ctl)); gp->chol_ctl = nullptr; }
+        const size_t cap = 2 + 64 + (size_t)(gp->n_cap / 64 < 64 ? gp->n_cap / 64 : 64) * (gp->n_cap / 64 < 64 ? gp->n_cap / 64 : 64);
+        ALABI_HIP_CHECK(hipMalloc(&gp->chol_ctl, (cap > ctl_ints ? cap : ctl_ints) * sizeof(int)));
+        gp->chol_ctl_ints = cap > ctl_ints ? cap : ctl_ints;
+    }
+    const CholTask* tasks = nullptr;
+    int ntasks = 0, st;
+    if ((st = chol_task_list(nb, &tasks, &ntasks)) != ALABI_OK) return st;
+    ALABI_HIP_CHECK(hipMemsetAsync(gp->chol_ctl, 0, ctl_ints * sizeof(int), s));
+    ALABI_HIP_CHECK(hipMemsetAsync(gp->info, 0, sizeof(int), s));
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    int grid = ntasks < n_cu ? ntasks : n_cu;
+    int spin = 1 << 18;
+    if (const char* e2 = getenv("ALABI_CHOL_SPIN_LIMIT")) { const int v = atoi(e2); if (v > 0) spin = v; }
+    hipLaunchKernelGGL(chol_tasks_kernel, dim3(grid), dim3(256), 0, s, gp->L, ld, nb, tasks, ntasks, gp->chol_ctl, gp->info, gp->dinv, spin);
+    ALABI_LAUNCH_CHECK();
+#ifdef ALABI_CHOL_PROF
+    {
+        long long h[8];
+        (void)hipMemcpyAsync(h, gp->chol_ctl + ((2 + nb * nb + 1) & ~1), sizeof(h), hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        if (h[6] > 0)
+            fprintf(stderr, "[chol_tasks_kernel] per CHAIN (us): wait %.2f loads %.2f trsm %.2f store+publish %.2f mfma %.2f potrf %.2f store+publish %.2f (n=%lld)\n",
+                    0.01 * h[7] / h[6], 0.01 * h[0] / h[6], 0.01 * h[1] / h[6], 0.01 * h[2] / h[6], 0.01 * h[3] / h[6], 0.01 * h[4] / h[6],
+                    0.01 * h[5] / h[6], h[6]);
+    }
+#endif
+    *launched = 1;
+    return ALABI_OK;
 }
 
 int launch_cholesky(alabi_gp* gp, hipStream_t s) {

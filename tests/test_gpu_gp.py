@@ -596,3 +596,43 @@ def test_cholesky_panel_path(torch_gpu, monkeypatch, N, panel):
     assert np.max(np.abs(facs["panel"][0] - facs["rank64"][0])) <= 1e-9 * np.max(np.abs(facs["rank64"][0]))
     assert abs(facs["panel"][1] - o.compute(X).log_likelihood(y)) <= 1e-9 * abs(facs["rank64"][1])
     assert np.max(np.abs(facs["panel"][2][1] - facs["rank64"][2][1])) <= 1e-8 * np.exp(h["log_amp"])
+
+
+@pytest.mark.parametrize("N", [130, 200, 705, 2000, 4096])
+def test_cholesky_task_queue(torch_gpu, monkeypatch, N):
+    """Up to 64 block columns the factorisation is ONE launch: persistent workgroups draw tile tasks (chain / panel solve /
+    update) from a queue and hand tiles over through versioned write-through stores.  Same factor as the launch-per-step path
+    to rounding, K reproduced, a non-positive-definite matrix reported with LAPACK's pivot index, and a wait that runs out
+    falls back to the step-by-step path with the same result."""
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    X, y, h = make_problem(N, 6, 70 + N)
+    o = OracleGP(6, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"])
+    K = o.get_matrix(X)
+    facs = {}
+    for tag, env in (("queue", "1"), ("steps", "0")):
+        monkeypatch.setenv("ALABI_CHOL_TASKS", env)
+        g = HipGP(6, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+        L = g.solver.get_factor().cpu().numpy()
+        assert np.allclose(np.triu(L, 1), 0.0)
+        assert np.max(np.abs(L @ L.T - K)) <= 1e-12 * np.max(np.abs(K)), tag
+        facs[tag] = (L, g.log_likelihood(y), g.predict(y, X[:64] + 0.01, return_var=True))
+    assert np.max(np.abs(facs["queue"][0] - facs["steps"][0])) <= 1e-10 * np.max(np.abs(facs["steps"][0]))
+    assert abs(facs["queue"][1] - facs["steps"][1]) <= 1e-10 * abs(facs["steps"][1])
+    assert np.max(np.abs(facs["queue"][2][1] - facs["steps"][2][1])) <= 1e-9 * np.exp(h["log_amp"])
+    monkeypatch.setenv("ALABI_CHOL_TASKS", "1")
+    if N == 705:
+        # not positive definite: numerically identical points without a nugget -> reported, not hung
+        Xd = np.zeros((N, 6)); Xd[:, 0] = np.arange(N) * 1e-9
+        for env in ("1", "0"):
+            monkeypatch.setenv("ALABI_CHOL_TASKS", env)
+            gd = HipGP(6, 0.0, -80.0, 0.0, np.zeros(6))
+            with pytest.raises(np.linalg.LinAlgError):
+                gd.compute(Xd)
+            assert gd.compute(Xd, quiet=True) is False
+        # a wait that runs out: fall back, same factor
+        monkeypatch.setenv("ALABI_CHOL_TASKS", "1")
+        monkeypatch.setenv("ALABI_CHOL_SPIN_LIMIT", "1")
+        g2 = HipGP(6, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g2.compute(X)
+        assert np.array_equal(g2.solver.get_factor().cpu().numpy(), facs["steps"][0])
+        monkeypatch.delenv("ALABI_CHOL_SPIN_LIMIT")

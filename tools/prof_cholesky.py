@@ -11,12 +11,14 @@ for N in sizes:
     rng = np.random.RandomState(N)
     X = rng.uniform(-3, 3, (N, d))
     log_M = np.log(np.full(d, 30.0 if d == 10 else 60.0))
-    for tag, panel, la in (("rank-64", "0", "1"), ("panel-4 serial", "4", "0"), ("panel-4 look-ahead", "4", "1"), ("panel-2 look-ahead", "2", "1")):
-        os.environ["ALABI_CHOL_PANEL"] = panel; os.environ["ALABI_CHOL_LOOKAHEAD"] = la
+    variants = [("task queue (one launch)", "0", "1", "1")] if N <= 4096 else []
+    variants += [("rank-64", "0", "1", "0"), ("panel-4 serial", "4", "0", "0"), ("panel-4 look-ahead", "4", "1", "0"), ("panel-2 look-ahead", "2", "1", "0")]
+    for tag, panel, la, tq in variants:
+        os.environ["ALABI_CHOL_PANEL"] = panel; os.environ["ALABI_CHOL_LOOKAHEAD"] = la; os.environ["ALABI_CHOL_TASKS"] = tq
         gp = HipGP(d, 0.0, -12.0, 0.0, log_M)
         gp.compute(X); torch.cuda.synchronize()
         best = 1e9
         for _ in range(4):
             t0 = time.perf_counter(); gp.compute(X); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-        print(f"N={N:6d} {tag:20s}: {best*1e3:8.3f} ms  {N**3/3/best/1e12:6.2f} TFLOP/s", flush=True)
+        print(f"N={N:6d} {tag:24s}: {best*1e3:8.3f} ms  {N**3/3/best/1e12:6.2f} TFLOP/s", flush=True)
         del gp
