@@ -286,3 +286,46 @@ def test_fit_predict_equals_separate_calls():
     bad.set_parameter_vector(np.r_[h["mean"], -40.0, h["log_amp"], h["log_M"]])
     ll, mu = bad.fit_predict_device(dev(Xd), dev(np.r_[y[:10], y[:10]]), dev(Xs))
     assert (ll == -np.inf and mu is None) or np.isfinite(ll)           # either rejected as not PD or factorised with rounding luck
+
+
+@pytest.mark.parametrize("scalers", ["identity", "minmax+standard", "nlog"])
+def test_surrogate_log_likelihood_vs_oracle_composite(tmp_path, scalers):
+    """surrogate_log_likelihood (core.py:1446-1508) and the cached callable (core.py:53-122) against the oracle's restatement
+    of the scale -> predict -> un-scale composite on an OracleGP carrying the same hyper-parameters: scalar for a 1-D input,
+    arrays for 2-D, the two variance conventions, affine scalers and the reference's non-affine nlog_scaler."""
+    from sklearn.preprocessing import MinMaxScaler, StandardScaler
+    from alabi_amd import SurrogateModel, utility as ut
+    from alabi_amd.benchmarks import gaussian_2d
+    from oracle.gp_oracle import OracleGP
+    from oracle import surrogate_oracle as so
+    fn = (lambda th: float(gaussian_2d["fn"](th)) - 5.0) if scalers == "nlog" else gaussian_2d["fn"]
+    kw = {} if scalers == "identity" else (dict(theta_scaler=MinMaxScaler(), y_scaler=StandardScaler()) if scalers != "nlog"
+                                           else dict(y_scaler=ut.nlog_scaler))
+    sm = SurrogateModel(lnlike_fn=fn, bounds=gaussian_2d["bounds"], savedir=str(tmp_path), verbose=False, random_state=8, cache=False)
+    sm.init_samples(ntrain=90)
+    sm.init_gp(hyperopt_method="ml", gp_nopt=1, optimizer_kwargs={"maxiter": 10}, **kw)
+    p = sm.gp.get_parameter_vector()
+    o = OracleGP(2, p[0], p[1], p[2], p[3:]).compute(sm._theta)
+    t = np.random.RandomState(0).uniform(0.05, 0.95, (40, 2))
+    ref = so.surrogate_log_likelihood(o, sm._y, sm.theta_scaler, sm.y_scaler, t)
+    got = sm.surrogate_log_likelihood(t)
+    assert got.shape == ref.shape == (40,)
+    assert np.max(np.abs(got - ref) / (np.abs(ref) + 1)) <= 1e-8
+    one = sm.surrogate_log_likelihood(t[3])
+    assert np.ndim(one) == 0 and abs(one - so.surrogate_log_likelihood(o, sm._y, sm.theta_scaler, sm.y_scaler, t[3])) <= 1e-8 * (abs(one) + 1)
+    mu, var = sm.surrogate_log_likelihood(t, return_var=True)
+    mu_o, var_o = so.surrogate_log_likelihood(o, sm._y, sm.theta_scaler, sm.y_scaler, t, return_var=True)
+    assert np.max(np.abs(mu - mu_o) / (np.abs(mu_o) + 1)) <= 1e-8
+    assert np.max(np.abs(var - var_o)) <= 1e-6 * max(np.max(np.abs(var_o)), np.exp(p[2]), 1.0)
+    for rv in (False, True):
+        cached = sm.create_cached_surrogate_likelihood(return_var=rv)
+        c_got = cached(t)
+        c_ref = so.cached_surrogate_call(o, sm._y, sm.theta_scaler, sm.y_scaler, 2, t, return_var=rv)
+        if rv:
+            assert np.max(np.abs(c_got[0] - c_ref[0]) / (np.abs(c_ref[0]) + 1)) <= 1e-8
+            sf = sm.y_scaler.scale_[0] ** 2 if getattr(sm.y_scaler, "scale_", None) is not None else \
+                float(((sm.y_scaler.inverse_transform(np.array([[0.0], [1e-6]]))[1] - sm.y_scaler.inverse_transform(np.array([[0.0], [1e-6]]))[0]) / 1e-6) ** 2)
+            assert np.max(np.abs(c_got[1] - c_ref[1])) <= 1e-6 * np.exp(p[2]) * sf          # 1e-6 of the (un-scaled) prior variance
+        else:
+            assert np.max(np.abs(c_got - c_ref) / (np.abs(c_ref) + 1)) <= 1e-8
+        assert np.ndim(cached(t[0]) if not rv else cached(t[0])[0]) == 0
