@@ -532,6 +532,7 @@ struct StreamArgs {
     unsigned long long* n_accept;
     const long long* run_state;
     int K, W, n0, d, Npad, thin_by, spin_limit, has_prior;
+    int poll_sleep;              // s_sleep(1) units between two looks of ens_stream_kernel's poll (0: none)
     long long* dbg;              // nullable: per-workgroup counters of ens_spec_kernel (ALABI_SPEC_DBG=1)
     unsigned long long* prop;    // nullable: [(K+1)][E*W][d] published proposals of ens_spec_kernel (sentinel-filled like hist)
     double amp, mean, prior_const;
@@ -713,6 +714,7 @@ ens_stream_kernel(StreamArgs p) {
                     ok = 0;
                     break;
                 }
+                for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
             }
 #endif
 #ifdef ALABI_STREAM_PROF
@@ -1195,6 +1197,7 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
     if (const char* env = getenv("ALABI_ENS_SPIN_LIMIT")) { const int v = atoi(env); if (v > 0) a.spin_limit = v; }   // tests: force a time-out
     a.amp = e->lp_scale * exp(gp->log_amp); a.mean = fma(e->lp_scale, gp->mean, e->lp_shift); a.kf = gp->kf;
     a.has_prior = e->has_prior; a.prior_const = e->prior_const;
+    if (const char* env = getenv("ALABI_ENS_POLL_SLEEP")) a.poll_sleep = atoi(env);
     const int db = dim_bucket(e->d);
     // lanes x pairs-per-lane cover Npad/2 point pairs; the launch-per-half-step kernel's lane -> point map (and so its
     // summation order) is reproduced exactly because both run with e->threads compute lanes.
