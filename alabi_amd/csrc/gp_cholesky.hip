@@ -46,15 +46,16 @@ __device__ inline void tile_update_16(double (*C)[LD], int cr, int cc, double (*
     for (int i = 0; i < 4; ++i) C[cr + lk + 4 * i][cc + lr] = acc[i];
 }
 
-// 1/sqrt(piv) from the hardware estimate + two Newton steps, L_jj = piv * rinv with one correction, then the
-// reciprocal refined: ~12 dependent ops instead of an IEEE sqrt followed by an IEEE division.
+// 1/sqrt(piv) from the hardware estimate r0 (relative error <= 5.2e-8, tools/micro/rsq_accuracy) and ONE third-order step:
+// with e = 1 - piv r0^2, 1/sqrt(piv) = r0 (1 + e/2 + 3 e^2/8 + O(e^3)), the dropped term is ~1e-22.  Four dependent
+// operations after the estimate (two Newton steps are six); the slab recurrence scales its column by this value, so it sits
+// on the critical chain of every pivot.  L_jj = piv * rinv with one correction is off that chain.
 __device__ inline void pivot_factors(double piv, double& ljj, double& rinv) {
-    rinv = __builtin_amdgcn_rsq(piv);
-    rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
-    rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+    const double r0 = __builtin_amdgcn_rsq(piv);
+    const double e = fma(-(piv * r0), r0, 1.0);
+    rinv = fma(r0 * e, fma(0.375, e, 0.5), r0);
     ljj = piv * rinv;
     ljj = fma(0.5 * rinv, fma(-ljj, ljj, piv), ljj);
-    rinv = fma(rinv, fma(-ljj, rinv, 1.0), rinv);
 }
 
 // Diagonal block held in LDS (row stride LD doubles), factorised in place by ONE wavefront in 16-column slabs.  Inside a

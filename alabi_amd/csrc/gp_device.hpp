@@ -38,6 +38,7 @@ __host__ __device__ inline int dim_bucket(int d) {
 // (truncation 4e-18), scaling by ldexp; large r2 underflows to 0 through ldexp.  Maximum error 1.23 ulp against exp of the
 // exact argument on 6e5 samples in [0, 1500] (NumPy's exp: 1.18 ulp on the same samples).  Every kernel of the library uses
 // this one function for the squared-exponential, so their results stay mutually consistent.
+// Range: r2 < ~1e40 (beyond that the reduction's residual overflows the polynomial; coordinates of 1e20 length scales).
 __device__ inline double exp_neg_half(double r2) {
     const double x = -0.5 * r2;
     const double n = rint(x * 1.4426950408889634);
@@ -101,6 +102,28 @@ __device__ inline double exp_tab32(double x, const double* tab) {
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return ldexp(p * t, ki >> 5);
+}
+
+// 2^(s / 64) = exp(s ln2 / 64) for an argument ALREADY multiplied by 64 / ln2 (the matrix-core predict kernel folds the factor
+// into its query operand, so the product arrives scaled), with a 64-entry table tab[j] = 2^(j/64) in LDS.  s = 64 n + j + r
+// with r = s - rint(s) exact and |r| <= 1/2: rint comes from adding 1.5 * 2^52, whose low word then holds 64 n + j as an
+// integer (no convert instruction); degree-5 Taylor polynomial in r (truncation 3.5e-17); result 2^n tab[j] p(r).  The clamp
+// keeps the integer inside 32 bits; everything below 2^-1094 is 0 through ldexp anyway.  11 instructions on the fp64 pipe
+// against 13 for exp_tab32 and 19 for exp_direct.
+#define ALABI_EXP2S_SCALE 92.33248261689366                          /* 64 / ln2 */
+__device__ inline double exp2s_tab64(double s, const double* tab) {
+    s = fmax(s, -70016.0);
+    const double t = s + 0x1.8p52;
+    const double r = s - (t - 0x1.8p52);
+    const int ki = __double2loint(t);
+    const double tj = tab[ki & 63];
+    double p = 0x1.5d87fe78a6731p-40;                               // (ln2/64)^5 / 5!
+    p = fma(p, r, 0x1.3b2ab6fba4e77p-31);
+    p = fma(p, r, 0x1.c6b08d704a0c0p-23);
+    p = fma(p, r, 0x1.ebfbdff82c58fp-15);
+    p = fma(p, r, 0x1.62e42fefa39efp-7);
+    p = fma(p, r, 1.0);
+    return ldexp(p * tj, ki >> 6);
 }
 
 // GENERIC = false compiles the squared-exponential alone (no run-time switch in the hot loops).

@@ -439,14 +439,16 @@ def main():
                                   ("predict_meanvar_pts_per_s_M65536", 65536, True), ("predict_meanvar_pts_per_s_M1e4", 10_000, True),
                                   ("predict_meanvar_pts_per_s_M256", 256, True)):
                 Xs = lo + (hi - lo) * torch.rand((M, d), dtype=torch.float64, device="cuda", generator=gen)
-                gp.predict_device(y_dev, Xs, return_var=var); torch.cuda.synchronize()
-                reps = (2 if var else 3) if M > 100000 else (20 if M > 1000 else 200)
-                t1 = time.perf_counter()
+                gp.predict_device(y_dev, Xs, return_var=var); gp.predict_device(y_dev, Xs, return_var=var); torch.cuda.synchronize()
+                reps = (2 if var else 10) if M > 100000 else (20 if M > 1000 else 200)
+                # HIP events on the stream the kernels are launched on (torch's current stream): GPU time of `reps` calls
+                ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
                 for _ in range(reps):
                     gp.predict_device(y_dev, Xs, return_var=var)
-                torch.cuda.synchronize()
-                extras[label] = M * reps / (time.perf_counter() - t1)
-            # secondary rooflines (wall-clock around the call incl. launch overhead; kernel-only times are in profiles/).
+                ev1.record(); torch.cuda.synchronize()
+                extras[label] = M * reps / (ev0.elapsed_time(ev1) * 1e-3)
+            # secondary rooflines (HIP-event time over the calls, launch gaps included; kernel-only times are in profiles/).
             # predict_var: per query point N^2 flops for the triangular solve L^-1 k* (N^2/2 fma) + N(2d+3) for k*.
             pv_flops = 65536.0 * (N * N + N * (2 * d + 3))
             pv_tf = pv_flops * extras["predict_meanvar_pts_per_s_M65536"] / 65536.0 / 1e12
