@@ -164,9 +164,59 @@ potrf_diag_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ info
         if (lane <= r) Ab[(size_t)r * ld + lane] = Ls[r][lane];
 }
 
+// One row's recurrence over a 16-column slab of X L_kk^T = B (right-looking along the row: two dependent operations per
+// column -- scale, first update -- and the other updates fill their shadow).  The 120 strictly-lower entries of the slab's
+// triangle and the 16 reciprocals are wave-uniform LDS broadcasts; they are fetched in four column groups (3, 3, 4, 6
+// columns: 42, 33, 30, 15 entries), each while the group before it is being applied, so the chain never waits for LDS and at
+// most two groups are live: ~215 registers instead of 364 for fetching all 120 up front.  That matters beyond this kernel:
+// a workgroup of the panel chain has to fit into the hole one retired workgroup of the bulk trailing update leaves on a SIMD
+// (512 - 232 registers), or the chain cannot overlap that update at all.  sched_barrier keeps the compiler from sinking a
+// group's reads next to their uses.
+template <int J0, int J1, int LD>
+__device__ inline void trsm_group_fetch(double (*lkk)[LD], const double* di, int c0, double* lg, double* dg) {
+    int q = 0;
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+        dg[j - J0] = di[c0 + j];
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) lg[q++] = lkk[c0 + k][c0 + j];
+    }
+}
+template <int J0, int J1>
+__device__ inline void trsm_group_apply(double* b, const double* lg, const double* dg) {
+    int q = 0;
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+        b[j] *= dg[j - J0];
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) b[k] = fma(-b[j], lg[q++], b[k]);
+    }
+}
+template <int LD>
+__device__ inline void trsm_slab_row(double (*lkk)[LD], double (*bs)[LD], const double* di, int row, int c0) {
+    double b[16], l0[42], l1[33], l2[30], l3[15], d0[3], d1[3], d2[4], d3[6];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) b[j] = bs[row][c0 + j];
+    trsm_group_fetch<0, 3, LD>(lkk, di, c0, l0, d0);
+    __builtin_amdgcn_sched_barrier(0);
+    trsm_group_fetch<3, 6, LD>(lkk, di, c0, l1, d1);
+    trsm_group_apply<0, 3>(b, l0, d0);
+    __builtin_amdgcn_sched_barrier(0);
+    trsm_group_fetch<6, 10, LD>(lkk, di, c0, l2, d2);
+    trsm_group_apply<3, 6>(b, l1, d1);
+    __builtin_amdgcn_sched_barrier(0);
+    trsm_group_fetch<10, 16, LD>(lkk, di, c0, l3, d3);
+    trsm_group_apply<6, 10>(b, l2, d2);
+    __builtin_amdgcn_sched_barrier(0);
+    trsm_group_apply<10, 16>(b, l3, d3);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bs[row][c0 + j] = b[j];
+}
+
 // X * L_kk^T = B for 64 rows; four wavefronts, wave w owns rows 16w..16w+15.  16-column slabs: inside a slab one lane
-// runs one row's recurrence (L_kk read from LDS as broadcasts, divisions are multiplications by dinv, no cross-lane
-// traffic); the slab's effect on the remaining columns is a rank-16 update on the matrix cores, one row tile per wave.
+// runs one row's recurrence (trsm_slab_row: L_kk read from LDS as broadcasts, divisions are multiplications by dinv, no
+// cross-lane traffic); the slab's effect on the remaining columns is a rank-16 update on the matrix cores, one row tile per
+// wave.
 __global__ void __launch_bounds__(256)
 trsm_panel_kernel(double* __restrict__ A, int ld, int kb, const double* __restrict__ dinv) {
     __shared__ double lkk[64][65];
@@ -188,33 +238,7 @@ trsm_panel_kernel(double* __restrict__ A, int ld, int kb, const double* __restri
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int c0 = 16 * s;
-        if (lane < 16) {
-            // every operand of the slab's recurrence is read into registers first (sched_barrier keeps the compiler from
-            // sinking the reads back next to their uses): the chain below then contains no LDS round trip
-            double b[16], dj[16], lreg[120];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { b[j] = bs[row][c0 + j]; dj[j] = di[c0 + j]; }
-            {
-                int q = 0;
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-#pragma unroll
-                    for (int k = j + 1; k < 16; ++k) lreg[q++] = lkk[c0 + k][c0 + j];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // right-looking along the row: two dependent operations per column (scale, first update), the rest fills in
-            {
-                int q = 0;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    b[j] *= dj[j];
-#pragma unroll
-                    for (int k = j + 1; k < 16; ++k) b[k] = fma(-b[j], lreg[q++], b[k]);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) bs[row][c0 + j] = b[j];
-        }
+        if (lane < 16) trsm_slab_row<65>(lkk, bs, di, row, c0);
         __syncthreads();
         // B[rows of this wave, later slabs] -= X_s * L_kk[later rows, slab]^T
 #pragma unroll
@@ -312,7 +336,14 @@ syrk_update_kernel(double* __restrict__ A, int ld, int kb, int* __restrict__ inf
 // doubles: conflict-free ds_read_b64 for the fragment layout), the next slice is fetched into registers while the current
 // one is multiplied; one barrier per slice.  Tile columns [tc0, tc1) of the trailing matrix are processed (look-ahead: the
 // columns of the next panel on the main stream, the rest on a second stream).
-__global__ void __launch_bounds__(256)
+// FUSE_POTRF = false is the bulk instantiation (the look-ahead remainder): without the factorisation code it stays below
+// 256 registers, so TWO workgroups share a CU and one's barriers and fetch waits hide behind the other's MFMAs (with the
+// fused code in the same kernel the allocation was 392 registers: one wave per SIMD, 48 % matrix-core occupancy,
+// profiles/r02_cholesky_n10000_timeline.txt).  Tiles that lie wholly inside the matrix (all but the last tile row) take
+// loads and stores without per-element guards; a wave whose 64 x 64 quadrant is the upper block of a diagonal tile idles.
+// The accumulators hold -C, so the products are added as they come and the sign is restored with the store.
+template <bool FUSE_POTRF>
+__global__ void __launch_bounds__(256, FUSE_POTRF ? 1 : 2)
 syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int row0, int tc0, int tc1, int ntr,
                   int* __restrict__ info, double* __restrict__ dinv) {
     __shared__ __attribute__((aligned(16))) double Ps[2][2][128][18];   // [buffer][I / J][row][k]
@@ -323,16 +354,29 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
     const int ri = row0 + 128 * ti, rj = row0 + 128 * tj;            // first row of P_I / P_J (= first column of the C tile)
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
     const int wr = w >> 1, wc = w & 1;
-    // staging map: thread -> (row r8 + 32 pass, 2 consecutive k), 8 threads per 128-byte row slice
+    const bool full = ri + 128 <= n;                                 // rj <= ri: the tile needs no row / column guards
+    const bool quad = ti > tj || wc <= wr;                           // this wave's quadrant is part of the lower block triangle
+    // staging map: thread -> (row sr + 32 pass, 2 consecutive k), 8 threads per 128-byte row slice
     const int sr = tid >> 3, sk = (tid & 7) * 2;
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     f64x2 gi[4], gj[4];
+    const double* pI = A + (size_t)(ri + sr) * ld + col0 + sk;
+    const double* pJ = A + (size_t)(rj + sr) * ld + col0 + sk;
+    const size_t rs = (size_t)32 * ld;
     auto fetch = [&](int k0) {
+        if (full) {
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int r = sr + 32 * ps;
-            gi[ps] = (ri + r < n) ? *reinterpret_cast<const f64x2*>(A + (size_t)(ri + r) * ld + col0 + k0 + sk) : f64x2{0.0, 0.0};
-            gj[ps] = (rj + r < n) ? *reinterpret_cast<const f64x2*>(A + (size_t)(rj + r) * ld + col0 + k0 + sk) : f64x2{0.0, 0.0};
+            for (int ps = 0; ps < 4; ++ps) {
+                gi[ps] = *reinterpret_cast<const f64x2*>(pI + ps * rs + k0);
+                gj[ps] = *reinterpret_cast<const f64x2*>(pJ + ps * rs + k0);
+            }
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int r = sr + 32 * ps;
+                gi[ps] = (ri + r < n) ? *reinterpret_cast<const f64x2*>(pI + ps * rs + k0) : f64x2{0.0, 0.0};
+                gj[ps] = (rj + r < n) ? *reinterpret_cast<const f64x2*>(pJ + ps * rs + k0) : f64x2{0.0, 0.0};
+            }
         }
     };
     auto stage = [&](int b) {
@@ -344,41 +388,55 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
         }
     };
     fetch(0);
-    // accumulators start from C (rows ri + 64 wr + 16 m + lk + 4 i, columns rj + 64 wc + 16 nn + lr)
+    // accumulators start from -C (rows ri + 64 wr + 16 m + lk + 4 i, columns rj + 64 wc + 16 nn + lr)
+    double* Cw = A + (size_t)(ri + 64 * wr + lk) * ld + rj + 64 * wc + lr;
     v4f64 acc[4][4];
+    if (full && quad) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int r = ri + 64 * wr + 16 * m + lk + 4 * i, c = rj + 64 * wc + 16 * nn + lr;
-                acc[m][nn][i] = (r < n && c < n && (c >> 6) <= (r >> 6)) ? A[(size_t)r * ld + c] : 0.0;
+                const double* row = Cw + (size_t)(16 * m + 4 * i) * ld;
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) acc[m][nn][i] = -row[16 * nn];
             }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = ri + 64 * wr + 16 * m + lk + 4 * i, c = rj + 64 * wc + 16 * nn + lr;
+                    acc[m][nn][i] = (quad && r < n && c < n) ? -A[(size_t)r * ld + c] : 0.0;
+                }
+    }
     stage(0);
     __syncthreads();
     const int nslices = kp / 16;
     for (int sl = 0; sl < nslices; ++sl) {
         const int b = sl & 1;
         if (sl + 1 < nslices) fetch(16 * (sl + 1));
+        if (quad) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            double a[4], bb[4];
+            for (int kk = 0; kk < 4; ++kk) {
+                double a[4], bb[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = -Ps[b][0][64 * wr + 16 * m + lr][4 * kk + lk];
+                for (int m = 0; m < 4; ++m) a[m] = Ps[b][0][64 * wr + 16 * m + lr][4 * kk + lk];
 #pragma unroll
-            for (int nn = 0; nn < 4; ++nn) bb[nn] = Ps[b][1][64 * wc + 16 * nn + lr][4 * kk + lk];
+                for (int nn = 0; nn < 4; ++nn) bb[nn] = Ps[b][1][64 * wc + 16 * nn + lr][4 * kk + lk];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int nn = 0; nn < 4; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], bb[nn], acc[m][nn], 0, 0, 0);
+                    for (int nn = 0; nn < 4; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], bb[nn], acc[m][nn], 0, 0, 0);
+            }
         }
         if (sl + 1 < nslices) stage(b ^ 1);
         __syncthreads();
     }
     // The first tile holds the diagonal block of the NEXT panel in the quadrant of wave 0: it is complete now, so it is
     // factorised on the spot (potrf_tile_lds_wg, all four waves) instead of by a launch of its own.
-    if (t == 0 && tc0 == 0 && dinv) {
+    if (FUSE_POTRF && t == 0 && tc0 == 0 && dinv) {
         double (*Ls)[66] = reinterpret_cast<double (*)[66]>(&Ps[0][0][0][0]);     // 64 x 66 doubles: fits the staging buffers
         if (w == 0) {
 #pragma unroll
@@ -386,7 +444,7 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) Ls[16 * m + lk + 4 * i][16 * nn + lr] = acc[m][nn][i];
+                    for (int i = 0; i < 4; ++i) Ls[16 * m + lk + 4 * i][16 * nn + lr] = -acc[m][nn][i];
         }
         __syncthreads();
         const double rinv = potrf_tile_lds_wg<66>(Ls, tid, row0 / 64, info);
@@ -397,19 +455,30 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[m][nn][i] = Ls[16 * m + lk + 4 * i][16 * nn + lr];
+                    for (int i = 0; i < 4; ++i) acc[m][nn][i] = -Ls[16 * m + lk + 4 * i][16 * nn + lr];
         }
     }
     // only block columns <= block rows belong to the factorisation: the upper 64-block of a diagonal tile is left alone
+    if (full && quad) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int r = ri + 64 * wr + 16 * m + lk + 4 * i, c = rj + 64 * wc + 16 * nn + lr;
-                if (r < n && c < n && (c >> 6) <= (r >> 6)) A[(size_t)r * ld + c] = acc[m][nn][i];
+                double* row = Cw + (size_t)(16 * m + 4 * i) * ld;
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) row[16 * nn] = -acc[m][nn][i];
             }
+    } else if (quad) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = ri + 64 * wr + 16 * m + lk + 4 * i, c = rj + 64 * wc + 16 * nn + lr;
+                    if (r < n && c < n) A[(size_t)r * ld + c] = -acc[m][nn][i];
+                }
+    }
 }
 
 
@@ -465,30 +534,7 @@ __device__ inline void trsm_tile_lds(double (*lkk)[66], double (*bs)[66], const 
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int c0 = 16 * s;
-        if (lane < 16) {
-            double b[16], dj[16], lreg[120];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { b[j] = bs[row][c0 + j]; dj[j] = di[c0 + j]; }
-            {
-                int q = 0;
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-#pragma unroll
-                    for (int k = j + 1; k < 16; ++k) lreg[q++] = lkk[c0 + k][c0 + j];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                int q = 0;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    b[j] *= dj[j];
-#pragma unroll
-                    for (int k = j + 1; k < 16; ++k) b[k] = fma(-b[j], lreg[q++], b[k]);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) bs[row][c0 + j] = b[j];
-        }
+        if (lane < 16) trsm_slab_row<66>(lkk, bs, di, row, c0);
         __syncthreads();
 #pragma unroll
         for (int t = s + 1; t < 4; ++t) tile_update_16<66>(bs, 16 * w, 16 * t, bs, 16 * w, lkk, 16 * t, c0, lane);
@@ -777,10 +823,11 @@ int launch_cholesky(alabi_gp* gp, hipStream_t s) {
     ALABI_HIP_CHECK(hipMemsetAsync(gp->info, 0, sizeof(int), s));
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, s, gp->L, ld, 0, gp->info, gp->dinv);
     // Block columns per panel (0: rank-64 updates of the whole trailing matrix).  Measured on MI355X (tools/prof_cholesky.py):
-    // the panel path wins from about N = 8000 on (N = 10000: 14.1 -> 12.3 ms); below that the extra launches per panel cost
-    // more than the trailing traffic they save (N = 5000: 3.1 vs 3.8 ms).
-    int panel = nb >= 128 ? 4 : 0;
-    if (const char* env = getenv("ALABI_CHOL_PANEL")) { const int v = atoi(env); if (v == 0 || v == 2 || v == 4) panel = v; }
+    // the panel path wins from about N = 8000 on (N = 10000: 14.3 -> 11.3 ms, N = 16000: 49.6 -> 31.4 ms with panels of 8;
+    // panels of 4: 11.8 / 33.0 ms); below that the extra launches per panel cost more than the trailing traffic they save
+    // (N = 5000: 3.2 vs 3.9 ms).
+    int panel = nb >= 128 ? 8 : 0;
+    if (const char* env = getenv("ALABI_CHOL_PANEL")) { const int v = atoi(env); if (v == 0 || v == 2 || v == 4 || v == 6 || v == 8) panel = v; }
     if (panel == 0) {
         for (int kb = 0; kb + 1 < nb; ++kb) {
             const int T = nb - kb - 1;
@@ -800,7 +847,11 @@ int launch_cholesky(alabi_gp* gp, hipStream_t s) {
     const char* la_env = getenv("ALABI_CHOL_LOOKAHEAD");
     const bool lookahead = !(la_env && la_env[0] == '0');
     if (lookahead && !side) {
-        ALABI_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        // lowest priority: the bulk update fills every CU (two workgroups each); whenever one of them retires, the waiting
+        // workgroups of the next panel's chain on the caller's stream are dispatched first
+        int prio_least = 0, prio_greatest = 0;
+        ALABI_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        ALABI_HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_least));
         for (int i = 0; i < 2; ++i) {
             ALABI_HIP_CHECK(hipEventCreateWithFlags(&ev_panel[i], hipEventDisableTiming));
             ALABI_HIP_CHECK(hipEventCreateWithFlags(&ev_rest[i], hipEventDisableTiming));
@@ -829,11 +880,11 @@ int launch_cholesky(alabi_gp* gp, hipStream_t s) {
             // the rest of the PREVIOUS panel's update touched the tiles we are about to update: wait for it
             if (rest_pending) ALABI_HIP_CHECK(hipStreamWaitEvent(s, ev_rest[(pi + 1) & 1], 0));
             ALABI_HIP_CHECK(hipEventRecord(ev_panel[pi & 1], s));                       // panel pi is final
-            hipLaunchKernelGGL(syrk_panel_kernel, dim3(tiles_in_cols(ntr, 0, tc_split)), dim3(256), 0, s, gp->L, ld, gp->Npad, 64 * p0, kp,
+            hipLaunchKernelGGL(syrk_panel_kernel<true>, dim3(tiles_in_cols(ntr, 0, tc_split)), dim3(256), 0, s, gp->L, ld, gp->Npad, 64 * p0, kp,
                                row0, 0, tc_split, ntr, gp->info, gp->dinv);
             if (tc_split < ntr) {
                 ALABI_HIP_CHECK(hipStreamWaitEvent(side, ev_panel[pi & 1], 0));
-                hipLaunchKernelGGL(syrk_panel_kernel, dim3(tiles_in_cols(ntr, tc_split, ntr)), dim3(256), 0, side, gp->L, ld, gp->Npad,
+                hipLaunchKernelGGL(syrk_panel_kernel<false>, dim3(tiles_in_cols(ntr, tc_split, ntr)), dim3(256), 0, side, gp->L, ld, gp->Npad,
                                    64 * p0, kp, row0, tc_split, ntr, ntr, gp->info, (double*)nullptr);
                 ALABI_HIP_CHECK(hipEventRecord(ev_rest[pi & 1], side));
                 rest_pending = true;
@@ -841,7 +892,7 @@ int launch_cholesky(alabi_gp* gp, hipStream_t s) {
                 rest_pending = false;
             }
         } else {
-            hipLaunchKernelGGL(syrk_panel_kernel, dim3(tiles_in_cols(ntr, 0, ntr)), dim3(256), 0, s, gp->L, ld, gp->Npad, 64 * p0, kp, row0,
+            hipLaunchKernelGGL(syrk_panel_kernel<true>, dim3(tiles_in_cols(ntr, 0, ntr)), dim3(256), 0, s, gp->L, ld, gp->Npad, 64 * p0, kp, row0,
                                0, ntr, ntr, gp->info, gp->dinv);
         }
     }

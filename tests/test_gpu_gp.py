@@ -570,7 +570,7 @@ def test_predict_mean_matrix_core_path(torch_gpu, monkeypatch, d, N, kernel):
     assert np.max(np.abs(mu_m[pick] - mu_o) / (np.abs(mu_o) + 1)) <= 1e-8
 
 
-@pytest.mark.parametrize("N,panel", [(705, "4"), (1500, "4"), (1100, "2"), (3200, "4")])
+@pytest.mark.parametrize("N,panel", [(705, "4"), (1500, "4"), (1100, "2"), (3200, "4"), (2900, "8"), (1700, "6")])
 def test_cholesky_panel_path(torch_gpu, monkeypatch, N, panel):
     """Panels of 2 / 4 block columns with one rank-128 / rank-256 trailing update (syrk_panel_kernel, 128 x 128 tiles) and
     look-ahead on a second stream: the factor reproduces K and equals the rank-64 factorisation to rounding (the path is the
