@@ -195,6 +195,7 @@ int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream) {
         ALABI_HIP_CHECK(hipStreamSynchronize(s));
         if (timed_out) {                                   // undefined matrix state: assemble and factorise again, step by step
             tasks_penalty.store(64, std::memory_order_relaxed);
+            if (getenv("ALABI_VERBOSE")) fprintf(stderr, "[alabi] task-queue Cholesky: a wait ran out (N=%d), falling back to the launch-per-step path\n", N);
             if ((st = launch_assemble(gp, s)) != ALABI_OK) return st;
             if ((st = launch_cholesky(gp, s)) != ALABI_OK) return st;
             ALABI_HIP_CHECK(hipMemcpyAsync(&info, gp->info, sizeof(int), hipMemcpyDeviceToHost, s));

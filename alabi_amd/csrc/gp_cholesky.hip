@@ -47,15 +47,45 @@ __device__ inline void tile_update_16(double (*C)[LD], int cr, int cc, double (*
 }
 
 // 1/sqrt(piv) from the hardware estimate r0 (relative error <= 5.2e-8, tools/micro/rsq_accuracy) and ONE third-order step:
-// with e = 1 - piv r0^2, 1/sqrt(piv) = r0 (1 + e/2 + 3 e^2/8 + O(e^3)), the dropped term is ~1e-22.  Four dependent
-// operations after the estimate (two Newton steps are six); the slab recurrence scales its column by this value, so it sits
-// on the critical chain of every pivot.  L_jj = piv * rinv with one correction is off that chain.
-__device__ inline void pivot_factors(double piv, double& ljj, double& rinv) {
+// with e = 1 - piv r0^2, 1/sqrt(piv) = r0 (1 + e/2 + 3 e^2/8 + O(e^3)), the dropped term is ~1e-22; measured 1.4e-16.
+// Four dependent operations after the estimate (two Newton steps are six); the slab recurrence scales its column by this
+// value, so it sits on the critical chain of every pivot.
+__device__ inline double pivot_rsqrt(double piv) {
     const double r0 = __builtin_amdgcn_rsq(piv);
     const double e = fma(-(piv * r0), r0, 1.0);
-    rinv = fma(r0 * e, fma(0.375, e, 0.5), r0);
-    ljj = piv * rinv;
-    ljj = fma(0.5 * rinv, fma(-ljj, ljj, piv), ljj);
+    return fma(r0 * e, fma(0.375, e, 0.5), r0);
+}
+
+// One 16-column slab of the diagonal block's factorisation; lane = row, a[j] = the row's entry in slab column j.  Right-
+// looking: pivot j is broadcast from its lane, the column is scaled by 1/sqrt(pivot) in EVERY lane -- the diagonal lane
+// thereby gets L_jj = piv / sqrt(piv) (1.1 ulp) without a select -- and the row's remaining slab columns take their rank-1
+// update at once, L[c0+k][c0+j] arriving by v_readlane from the lane that owns row c0+k.  The wave runs one instruction per
+// ~5 cycles whatever its kind, so the slab costs what it issues: no branch per pivot (a non-positive or NaN pivot is
+// replaced by 1 and its index kept in `bad`, 1-based within the tile, first one wins), no diagonal select, no per-pivot
+// bookkeeping of the reciprocals (potrf_dinv forms them from the finished diagonal).
+__device__ inline void potrf_slab(double (&a)[16], int c0, int& bad) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double piv = lane_bcast(a[j], c0 + j);
+        const bool ok = piv > 0.0;                          // false for NaN too
+        bad = (ok || bad != 0) ? bad : c0 + j + 1;
+        piv = ok ? piv : 1.0;
+        const double rinv = pivot_rsqrt(piv);
+        a[j] *= rinv;
+        double bc[16];                                      // all broadcasts of the column first: distinct SGPR pairs, so no
+#pragma unroll                                              // readlane -> use wait states between them and the FMAs
+        for (int k = j + 1; k < 16; ++k) bc[k] = lane_bcast(a[j], c0 + k);
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) a[k] = fma(-a[j], bc[k], a[k]);
+    }
+}
+
+// 1 / L_ll for the row of `lane` from the finished diagonal: hardware reciprocal (4.5e-8) + two Newton steps.
+__device__ inline double potrf_dinv(double lll) {
+    double r = __builtin_amdgcn_rcp(lll);
+    r = fma(fma(-lll, r, 1.0), r, r);
+    r = fma(fma(-lll, r, 1.0), r, r);
+    return r;
 }
 
 // Diagonal block held in LDS (row stride LD doubles), factorised in place by ONE wavefront in 16-column slabs.  Inside a
@@ -67,27 +97,14 @@ __device__ inline void pivot_factors(double piv, double& ljj, double& rinv) {
 // by one wave only when the caller's other waves wait at a later barrier, so plain wave-level ordering is used instead.
 template <int LD>
 __device__ inline double potrf_tile_lds(double (*Ls)[LD], int lane, int kb, int* __restrict__ info) {
-    double my_rinv = 1.0;
+    int bad = 0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int c0 = 16 * s;
         double a[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[j] = Ls[lane][c0 + j];      // row `lane`, this slab (rows < c0 carry unused values)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            double piv = lane_bcast(a[j], c0 + j);
-            if (!(piv > 0.0)) {  // also true for NaN
-                if (lane == 0) atomicCAS(info, 0, kb * 64 + c0 + j + 1);
-                piv = 1.0;
-            }
-            double ljj, rinv;
-            pivot_factors(piv, ljj, rinv);
-            a[j] = (lane == c0 + j) ? ljj : a[j] * rinv;
-            if (lane == c0 + j) my_rinv = rinv;
-#pragma unroll
-            for (int k = j + 1; k < 16; ++k) a[k] = fma(-a[j], lane_bcast(a[j], c0 + k), a[k]);
-        }
+        potrf_slab(a, c0, bad);
 #pragma unroll
         for (int j = 0; j < 16; ++j) Ls[lane][c0 + j] = a[j];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -102,7 +119,8 @@ __device__ inline double potrf_tile_lds(double (*Ls)[LD], int lane, int kb, int*
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    return my_rinv;
+    if (bad != 0 && lane == 0) atomicCAS(info, 0, kb * 64 + bad);
+    return potrf_dinv(Ls[lane][lane]);
 }
 
 // The same factorisation by a whole 256-thread workgroup: wave 0 runs the slab recurrences, the rank-16 tile updates
@@ -110,7 +128,7 @@ __device__ inline double potrf_tile_lds(double (*Ls)[LD], int lane, int kb, int*
 template <int LD>
 __device__ inline double potrf_tile_lds_wg(double (*Ls)[LD], int tid, int kb, int* __restrict__ info) {
     const int lane = tid & 63, w = tid >> 6;
-    double my_rinv = 1.0;
+    int bad = 0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int c0 = 16 * s;
@@ -118,20 +136,7 @@ __device__ inline double potrf_tile_lds_wg(double (*Ls)[LD], int tid, int kb, in
             double a[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) a[j] = Ls[lane][c0 + j];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double piv = lane_bcast(a[j], c0 + j);
-                if (!(piv > 0.0)) {  // also true for NaN
-                    if (lane == 0) atomicCAS(info, 0, kb * 64 + c0 + j + 1);
-                    piv = 1.0;
-                }
-                double ljj, rinv;
-                pivot_factors(piv, ljj, rinv);
-                a[j] = (lane == c0 + j) ? ljj : a[j] * rinv;
-                if (lane == c0 + j) my_rinv = rinv;
-#pragma unroll
-                for (int k = j + 1; k < 16; ++k) a[k] = fma(-a[j], lane_bcast(a[j], c0 + k), a[k]);
-            }
+            potrf_slab(a, c0, bad);
 #pragma unroll
             for (int j = 0; j < 16; ++j) Ls[lane][c0 + j] = a[j];
         }
@@ -146,7 +151,8 @@ __device__ inline double potrf_tile_lds_wg(double (*Ls)[LD], int tid, int kb, in
         __syncthreads();
     }
     __syncthreads();
-    return my_rinv;
+    if (w == 0 && bad != 0 && lane == 0) atomicCAS(info, 0, kb * 64 + bad);
+    return w == 0 ? potrf_dinv(Ls[lane][lane]) : 1.0;
 }
 
 // First diagonal block (the later ones are factorised inside syrk_update_kernel by the workgroup that finishes them).
@@ -777,12 +783,15 @@ static int chol_task_list(int nb, const CholTask** dev, int* count) {
 int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
     *launched = 0;
     const int ld = gp->Npad, nb = gp->Npad / 64;
-    // Opt-in (ALABI_CHOL_TASKS=1).  Measured at N = 2000 (tools/prof_cholesky.py, -DALABI_CHOL_PROF): 1.06 ms, the same as the
-    // launch-per-step path -- per block column the chain task spends 2.1 us fetching its three tiles, 8.6 us in the panel
-    // solve, 2.5 us in the diagonal update, 13.1 us in the 64-pivot factorisation and 2 us publishing: the two serial
-    // recurrences are 22 of its 28 us, the launch boundaries this design removes were only ~3 us per column.
+    // Default for 16..64 block columns (N = 961..4096; ALABI_CHOL_TASKS=0 / 1 forces it off / on for 3..64).  Measured
+    // (tools/prof_cholesky.py, assembly included): N = 1024 0.45 vs 0.48 ms launch-per-step, 2000 0.84 vs 0.94, 3072 1.29 vs
+    // 1.46, 4096 1.99 vs 2.12; below 1024 the two are equal.  Per block column the chain task spends ~2 us fetching its three
+    // tiles, ~8 us in the panel solve, 2.5 us in the diagonal update, ~10 us in the 64-pivot factorisation and 2 us
+    // publishing (-DALABI_CHOL_PROF): the two serial recurrences are most of it, the launch boundaries this design removes
+    // were ~3 us per column.
     const char* env = getenv("ALABI_CHOL_TASKS");
-    if (nb < 3 || nb > 64 || !(env && env[0] == '1')) return ALABI_OK;
+    const bool forced_on = env && env[0] == '1', forced_off = env && env[0] == '0';
+    if (nb < 3 || nb > 64 || forced_off || (!forced_on && nb < 16)) return ALABI_OK;
     const size_t ctl_ints = 2 + (size_t)nb * nb + 64;                  // + 64: phase timers of an ALABI_CHOL_PROF build
     if (gp->chol_ctl_ints < ctl_ints) {
         if (gp->chol_ctl) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); ALABI_HIP_CHECK(hipFree(gp->chol_ctl)); gp->chol_ctl = nullptr; }

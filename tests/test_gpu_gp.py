@@ -581,6 +581,7 @@ def test_cholesky_panel_path(torch_gpu, monkeypatch, N, panel):
     o = OracleGP(6, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"])
     K = o.get_matrix(X)
     facs = {}
+    monkeypatch.setenv("ALABI_CHOL_TASKS", "0")                  # these sizes would take the task-queue kernel by default
     for tag, env, la in (("panel", panel, "1"), ("panel-serial", panel, "0"), ("rank64", "0", "1")):
         if env is None:
             monkeypatch.delenv("ALABI_CHOL_PANEL", raising=False)
