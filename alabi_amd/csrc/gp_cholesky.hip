@@ -555,9 +555,66 @@ __shared__ double ct_T0[64][66];
 __shared__ double ct_T1[64][66];
 __shared__ double ct_T2[64][66];                                      // CHAIN: the diagonal tile, parked while the panel tile is solved
 __shared__ double ct_di[64];
-__device__ __attribute__((noinline)) void ct_trsm() { trsm_tile_lds(ct_T0, ct_T1, ct_di, threadIdx.x); }
-__device__ __attribute__((noinline)) double ct_potrf(int kb, int* info) {
-    return potrf_tile_lds_wg<66>(ct_T0, threadIdx.x, __builtin_amdgcn_readfirstlane(kb), info);
+// One 16-column slab of the panel solve (CHAIN: the slabs of L[k-1,k-1] arrive one by one, see ct_potrf_publish).
+template <int S>
+__device__ __attribute__((noinline)) void ct_trsm_slab() {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    if (lane < 16) trsm_slab_row<66>(ct_T0, ct_T1, ct_di, 16 * w + lane, 16 * S);
+    if (S == 3) return;
+    __syncthreads();
+#pragma unroll
+    for (int t = S + 1; t < 4; ++t) tile_update_16<66>(ct_T1, 16 * w, 16 * t, ct_T1, 16 * w, ct_T0, 16 * t, 16 * S, lane);
+}
+// The diagonal factorisation of CHAIN(k) (potrf_tile_lds_wg on ct_T0) that hands its result on SLAB BY SLAB: the 16 columns
+// of a slab are final for all 64 rows as soon as wave 0 has run the slab's recurrence, and the panel solve of the next chain
+// task consumes L[k,k] in exactly that order -- so wave 3, idle while wave 0 runs the next recurrence, writes the slab (and
+// its 16 reciprocals) through to memory and, one barrier later when its stores have drained, publishes sver[k] = slab + 1.
+// The next CHAIN task then solves slab s while this one factorises slab s + 1 .. 3 instead of starting after the whole tile.
+__device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, double* __restrict__ D, int ld, double* __restrict__ dinv,
+                                                            int* sver) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    kb = __builtin_amdgcn_readfirstlane(kb);
+    int bad = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c0 = 16 * s;
+        if (w == 0) {
+            double a[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = ct_T0[lane][c0 + j];
+            potrf_slab(a, c0, bad);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) ct_T0[lane][c0 + j] = a[j];
+        } else if (w == 3 && s > 0) {                          // slab s - 1 was written out in the previous round: publish it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(sver, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (s == 3) break;
+        __syncthreads();
+        if (w == 3) {                                          // rows c0.., columns c0..c0+15 (lower part), 4 rows x 128 B per store
+#pragma unroll
+            for (int e_ = 0; e_ < 16; ++e_) {
+                const int e = lane + 64 * e_, r = e >> 4, c = c0 + (e & 15);
+                if (c <= r)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(D + (size_t)r * ld + c),
+                                       (unsigned long long)__double_as_longlong(ct_T0[r][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane < 16)
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(dinv + kb * 64 + c0 + lane),
+                                   (unsigned long long)__double_as_longlong(potrf_dinv(ct_T0[c0 + lane][c0 + lane])), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int t = 0;
+#pragma unroll
+        for (int ti = s + 1; ti < 4; ++ti)
+#pragma unroll
+            for (int tk = s + 1; tk <= ti; ++tk, ++t)
+                if ((t & 3) == w) tile_update_16<66>(ct_T0, 16 * ti, 16 * tk, ct_T0, 16 * ti, ct_T0, 16 * tk, c0, lane);
+        __syncthreads();
+    }
+    __syncthreads();
+    if (w == 0 && bad != 0 && lane == 0) atomicCAS(info, 0, kb * 64 + bad);
+    return w == 0 ? potrf_dinv(ct_T0[lane][lane]) : 1.0;
 }
 // A tile in flight: all 16 loads of a thread are issued before the first one is consumed (several tiles are fetched
 // back to back and only then written to LDS: one memory round trip instead of one per tile)
@@ -584,7 +641,54 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
     double (*T0)[66] = ct_T0; double (*T1)[66] = ct_T1; double (*T2)[66] = ct_T2; double* di = ct_di;
     __shared__ int task_s[5];
     int* head = ctl; int* err = ctl + 1; int* ver = ctl + 2;          // ver[i * nb + j]
+    int* sver = ctl + 2 + nb * nb;                                    // sver[k]: slabs of L[k,k] published so far (0..4)
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+    // Panel solve of the tile in T1 against L[kk,kk], consumed slab by slab as its factorisation publishes them (sver[kk] =
+    // slabs written through so far): wait (bounded), fetch the slab's 64 x 16 block and its reciprocals, solve the slab,
+    // update the later slabs on the matrix cores.  false = a wait ran out (err is set; every thread returns).
+    auto solve_by_slabs = [&](int kk) -> bool {
+        const double* Lp = A + (size_t)(kk * 64) * ld + kk * 64;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(sver + kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sl + 1) {
+                    if (++spins > spin_limit || ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        task_s[4] = ntasks;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();                                          // also: the previous slab's tile updates are done
+            if (task_s[4] >= ntasks) return false;
+            {
+                unsigned long long v[4];
+#pragma unroll
+                for (int e_ = 0; e_ < 4; ++e_) {
+                    const int e = tid + 256 * e_;
+                    v[e_] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(Lp + (size_t)(e >> 4) * ld + 16 * sl + (e & 15)),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (tid < 16) di[16 * sl + tid] = __longlong_as_double((long long)__hip_atomic_load(
+                                  reinterpret_cast<const unsigned long long*>(dinv + kk * 64 + 16 * sl + tid), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+                for (int e_ = 0; e_ < 4; ++e_) {
+                    const int e = tid + 256 * e_;
+                    T0[e >> 4][16 * sl + (e & 15)] = __longlong_as_double((long long)v[e_]);
+                }
+            }
+            __syncthreads();
+            if (sl == 0) ct_trsm_slab<0>();
+            else if (sl == 1) ct_trsm_slab<1>();
+            else if (sl == 2) ct_trsm_slab<2>();
+            else ct_trsm_slab<3>();
+        }
+        __syncthreads();
+        return true;
+    };
     for (;;) {
         __syncthreads();                                              // the previous task is done with LDS and task_s
         if (tid == 0) {
@@ -601,14 +705,13 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
         // ---- dependencies: up to three (tile, version) pairs, polled by lanes 0..2 of wave 0
         if (w == 0) {
             int di_ = 0, dj_ = 0, need = 0;                           // lane 0 / 1 / 2
-            if (type == 0) {                                          // CHAIN(k): L[k-1,k-1] final, tile (k,k-1) and (k,k) at k-1
-                if (l == 0) { di_ = tk - 1; dj_ = tk - 1; need = tk; }
+            if (type == 0) {                                          // CHAIN(k): tile (k,k-1) and (k,k) at k-1
+                // (L[k-1,k-1] is NOT waited for here: its slabs are taken one by one below)
                 if (l == 1) { di_ = tk; dj_ = tk - 1; need = tk - 1; }
                 if (l == 2) { di_ = tk; dj_ = tk; need = tk - 1; }
                 if (tk == 0) need = 0;
                 if (tk == 0) { di_ = 0; dj_ = 0; }
-            } else if (type == 1) {                                   // TRSM(i,k): L[k,k] final, tile (i,k) at k
-                if (l == 0) { di_ = tk; dj_ = tk; need = tk + 1; }
+            } else if (type == 1) {                                   // TRSM(i,k): tile (i,k) at k (L[k,k] is taken slab by slab)
                 if (l == 1) { di_ = ti; dj_ = tk; need = tk; }
             } else {                                                  // UPDATE(i,j,k): (i,k), (j,k) final, tile (i,j) at k
                 if (l == 0) { di_ = ti; dj_ = tk; need = tk + 1; }
@@ -631,7 +734,7 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
         }
         __syncthreads();
 #ifdef ALABI_CHOL_PROF
-        if (tid == 0 && type == 0 && tk > 0) reinterpret_cast<long long*>(ctl + ((2 + nb * nb + 1) & ~1))[7] += __builtin_amdgcn_s_memrealtime() - pw0;
+        if (tid == 0 && type == 0 && tk > 0) reinterpret_cast<long long*>(ctl + ((2 + nb * nb + nb + 1) & ~1))[7] += __builtin_amdgcn_s_memrealtime() - pw0;
 #endif
         if (task_s[4] >= ntasks) return;                              // a wait ran out: every workgroup leaves at its next check
         if (type == 2) {
@@ -665,39 +768,35 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
             publish_version(ver + ti * nb + tj, tk + 1, tid);
         } else if (type == 1) {
             // ---------------- TRSM(i, k)
-            TileRegs ra, rb;
-            tile_fetch(ra, A + (size_t)(tk * 64) * ld + tk * 64, ld, tid);
-            tile_fetch(rb, A + (size_t)(ti * 64) * ld + tk * 64, ld, tid);
-            if (tid < 64) di[tid] = __longlong_as_double((long long)__hip_atomic_load(
-                              reinterpret_cast<const unsigned long long*>(dinv + tk * 64 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            tile_put(T0, ra, tid); tile_put(T1, rb, tid);
-            __syncthreads();
-            ct_trsm();
+            {
+                TileRegs rb;
+                tile_fetch(rb, A + (size_t)(ti * 64) * ld + tk * 64, ld, tid);
+                tile_put(T1, rb, tid);
+            }
+            if (!solve_by_slabs(tk)) return;
             tile_store_sc1(A + (size_t)(ti * 64) * ld + tk * 64, ld, T1, tid, false);
             publish_version(ver + ti * nb + tk, tk + 1, tid);
         } else {
             // ---------------- CHAIN(k)
             double* D = A + (size_t)(tk * 64) * ld + tk * 64;
 #ifdef ALABI_CHOL_PROF
-            long long* prof = reinterpret_cast<long long*>(ctl + ((2 + nb * nb + 1) & ~1));
+            long long* prof = reinterpret_cast<long long*>(ctl + ((2 + nb * nb + nb + 1) & ~1));
             const long long p0 = __builtin_amdgcn_s_memrealtime();
             long long p1 = p0, p2 = p0, p3 = p0, p4 = p0;
 #endif
             if (tk > 0) {
                 {
-                    TileRegs ra, rb, rc;
-                    tile_fetch(ra, A + (size_t)((tk - 1) * 64) * ld + (tk - 1) * 64, ld, tid);
+                    TileRegs rb, rc;
                     tile_fetch(rb, A + (size_t)(tk * 64) * ld + (tk - 1) * 64, ld, tid);
                     tile_fetch(rc, D, ld, tid);
-                    if (tid < 64) di[tid] = __longlong_as_double((long long)__hip_atomic_load(
-                                      reinterpret_cast<const unsigned long long*>(dinv + (tk - 1) * 64 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    tile_put(T0, ra, tid); tile_put(T1, rb, tid); tile_put(T2, rc, tid);
+                    tile_put(T1, rb, tid); tile_put(T2, rc, tid);
                 }
-                __syncthreads();
 #ifdef ALABI_CHOL_PROF
                 p1 = __builtin_amdgcn_s_memrealtime();
 #endif
-                ct_trsm();
+                // the panel solve, slab by slab as CHAIN(k-1) publishes the slabs of L[k-1,k-1] (bounded wait each)
+                if (!solve_by_slabs(tk - 1)) return;
+                __syncthreads();
 #ifdef ALABI_CHOL_PROF
                 p2 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -706,22 +805,33 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
 #ifdef ALABI_CHOL_PROF
                 p3 = __builtin_amdgcn_s_memrealtime();
 #endif
-                v4f64 acc[4];
+                // tile (k,k) -= X X^T, lower triangle only: its ten 16 x 16 tiles dealt 3 / 3 / 2 / 2 to the waves
+                //   w0: (0,0) (3,0) (3,1)   w1: (1,0) (1,1) (3,2)   w2: (2,0) (2,1)   w3: (2,2) (3,3)
+                const int nt = w < 2 ? 3 : 2;
+                const int rt0 = w == 0 ? 0 : w == 1 ? 1 : 2, ct0 = w == 3 ? 2 : 0;
+                const int rt1 = w == 0 ? 3 : w == 1 ? 1 : w == 2 ? 2 : 3, ct1 = w == 0 ? 0 : w == 3 ? 3 : 1;
+                const int rt2 = 3, ct2 = w == 0 ? 1 : 2;                // waves 0 and 1 only
+                v4f64 acc0, acc1, acc2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[n][i] = T2[16 * w + lk + 4 * i][16 * n + lr];
+                for (int i = 0; i < 4; ++i) {
+                    acc0[i] = T2[16 * rt0 + lk + 4 * i][16 * ct0 + lr];
+                    acc1[i] = T2[16 * rt1 + lk + 4 * i][16 * ct1 + lr];
+                    if (nt == 3) acc2[i] = T2[16 * rt2 + lk + 4 * i][16 * ct2 + lr];
+                }
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks) {
-                    const double a = -T1[16 * w + lr][4 * ks + lk];
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T1[16 * n + lr][4 * ks + lk], acc[n], 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-T1[16 * rt0 + lr][4 * ks + lk], T1[16 * ct0 + lr][4 * ks + lk], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-T1[16 * rt1 + lr][4 * ks + lk], T1[16 * ct1 + lr][4 * ks + lk], acc1, 0, 0, 0);
+                    if (nt == 3)
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-T1[16 * rt2 + lr][4 * ks + lk], T1[16 * ct2 + lr][4 * ks + lk], acc2, 0, 0, 0);
                 }
                 __syncthreads();                                      // everyone is done reading T0 (L[k-1,k-1])
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) T0[16 * w + lk + 4 * i][16 * n + lr] = acc[n][i];
+                for (int i = 0; i < 4; ++i) {
+                    T0[16 * rt0 + lk + 4 * i][16 * ct0 + lr] = acc0[i];
+                    T0[16 * rt1 + lk + 4 * i][16 * ct1 + lr] = acc1[i];
+                    if (nt == 3) T0[16 * rt2 + lk + 4 * i][16 * ct2 + lr] = acc2[i];
+                }
             } else {
                 tile_load_sc1(T0, D, ld, tid);
             }
@@ -729,14 +839,19 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
 #ifdef ALABI_CHOL_PROF
             p4 = __builtin_amdgcn_s_memrealtime();
 #endif
-            const double rinv = ct_potrf(tk, info);
+            const double rinv = ct_potrf_publish(tk, info, D, ld, dinv, sver + tk);
 #ifdef ALABI_CHOL_PROF
             const long long p5 = __builtin_amdgcn_s_memrealtime();
 #endif
             if (w == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dinv + tk * 64 + l),
                                            (unsigned long long)__double_as_longlong(rinv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             tile_store_sc1(D, ld, T0, tid, true);
-            publish_version(ver + tk * nb + tk, tk + 1, tid);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_store(sver + tk, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ver + tk * nb + tk, tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 #ifdef ALABI_CHOL_PROF
             if (tid == 0 && tk > 0) {   // 10-ns units: [0] loads [1] trsm [2] store+publish panel [3] mfma+park [4] potrf [5] store+publish diag [6] count [7] wait for deps
                 const long long p6 = __builtin_amdgcn_s_memrealtime();
@@ -784,18 +899,19 @@ int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
     *launched = 0;
     const int ld = gp->Npad, nb = gp->Npad / 64;
     // Default for 16..64 block columns (N = 961..4096; ALABI_CHOL_TASKS=0 / 1 forces it off / on for 3..64).  Measured
-    // (tools/prof_cholesky.py, assembly included): N = 1024 0.45 vs 0.48 ms launch-per-step, 2000 0.84 vs 0.94, 3072 1.29 vs
-    // 1.46, 4096 1.99 vs 2.12; below 1024 the two are equal.  Per block column the chain task spends ~2 us fetching its three
+    // (tools/prof_cholesky.py, assembly included): N = 1024 0.40 vs 0.48 ms launch-per-step, 2000 0.73 vs 0.93, 3072 1.24 vs
+    // 1.45, 4096 1.97 vs 2.11; below 1024 the two are equal.  Per block column the chain task spends ~2 us fetching its three
     // tiles, ~8 us in the panel solve, 2.5 us in the diagonal update, ~10 us in the 64-pivot factorisation and 2 us
     // publishing (-DALABI_CHOL_PROF): the two serial recurrences are most of it, the launch boundaries this design removes
     // were ~3 us per column.
     const char* env = getenv("ALABI_CHOL_TASKS");
     const bool forced_on = env && env[0] == '1', forced_off = env && env[0] == '0';
     if (nb < 3 || nb > 64 || forced_off || (!forced_on && nb < 16)) return ALABI_OK;
-    const size_t ctl_ints = 2 + (size_t)nb * nb + 64;                  // + 64: phase timers of an ALABI_CHOL_PROF build
+    const size_t ctl_ints = 2 + (size_t)nb * nb + nb + 66;             // + 66: alignment + phase timers of an ALABI_CHOL_PROF build
     if (gp->chol_ctl_ints < ctl_ints) {
         if (gp->chol_ctl) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); ALABI_HIP_CHECK(hipFree(gp->chol_ctl)); gp->chol_ctl = nullptr; }
-        const size_t cap = 2 + 64 + (size_t)(gp->n_cap / 64 < 64 ? gp->n_cap / 64 : 64) * (gp->n_cap / 64 < 64 ? gp->n_cap / 64 : 64);
+        const size_t cap_nb = gp->n_cap / 64 < 64 ? gp->n_cap / 64 : 64;
+        const size_t cap = 2 + 66 + cap_nb * cap_nb + cap_nb;
         ALABI_HIP_CHECK(hipMalloc(&gp->chol_ctl, (cap > ctl_ints ? cap : ctl_ints) * sizeof(int)));
         gp->chol_ctl_ints = cap > ctl_ints ? cap : ctl_ints;
     }
@@ -815,7 +931,7 @@ int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
 #ifdef ALABI_CHOL_PROF
     {
         long long h[8];
-        (void)hipMemcpyAsync(h, gp->chol_ctl + ((2 + nb * nb + 1) & ~1), sizeof(h), hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(h, gp->chol_ctl + ((2 + nb * nb + nb + 1) & ~1), sizeof(h), hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
         if (h[6] > 0)
             fprintf(stderr, "[chol_tasks_kernel] per CHAIN (us): wait %.2f loads %.2f trsm %.2f store+publish %.2f mfma %.2f potrf %.2f store+publish %.2f (n=%lld)\n",
