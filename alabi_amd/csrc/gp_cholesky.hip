@@ -60,17 +60,15 @@ __device__ inline double pivot_rsqrt(double piv) {
 // looking: pivot j is broadcast from its lane, the column is scaled by 1/sqrt(pivot) in EVERY lane -- the diagonal lane
 // thereby gets L_jj = piv / sqrt(piv) (1.1 ulp) without a select -- and the row's remaining slab columns take their rank-1
 // update at once, L[c0+k][c0+j] arriving by v_readlane from the lane that owns row c0+k.  The wave runs one instruction per
-// ~5 cycles whatever its kind, so the slab costs what it issues: no branch per pivot (a non-positive or NaN pivot is
-// replaced by 1 and its index kept in `bad`, 1-based within the tile, first one wins), no diagonal select, no per-pivot
-// bookkeeping of the reciprocals (potrf_dinv forms them from the finished diagonal).
-__device__ inline void potrf_slab(double (&a)[16], int c0, int& bad) {
+// ~5 cycles whatever its kind, so the slab costs what it issues: nothing per pivot but the chain itself -- no branch, no
+// diagonal select, no bookkeeping of the reciprocals (potrf_dinv forms them from the finished diagonal) and no test of the
+// pivot: a non-positive or non-finite pivot turns its own and every later column into NaN (rsq of it is NaN or inf, 0 * inf
+// = NaN), the earlier columns stay finite, so the FIRST diagonal entry that is not > 0 afterwards is LAPACK's `info`
+// (potrf_first_bad).
+__device__ inline void potrf_slab(double (&a)[16], int c0) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        double piv = lane_bcast(a[j], c0 + j);
-        const bool ok = piv > 0.0;                          // false for NaN too
-        bad = (ok || bad != 0) ? bad : c0 + j + 1;
-        piv = ok ? piv : 1.0;
-        const double rinv = pivot_rsqrt(piv);
+        const double rinv = pivot_rsqrt(lane_bcast(a[j], c0 + j));
         a[j] *= rinv;
         double bc[16];                                      // all broadcasts of the column first: distinct SGPR pairs, so no
 #pragma unroll                                              // readlane -> use wait states between them and the FMAs
@@ -78,6 +76,13 @@ __device__ inline void potrf_slab(double (&a)[16], int c0, int& bad) {
 #pragma unroll
         for (int k = j + 1; k < 16; ++k) a[k] = fma(-a[j], bc[k], a[k]);
     }
+}
+
+// 1-based index of the first diagonal entry of the finished tile that is not > 0 (NaN included), 0 if there is none; `lll` =
+// L[lane][lane], one full wave.
+__device__ inline int potrf_first_bad(double lll) {
+    const unsigned long long m = __ballot(!(lll > 0.0));
+    return m ? __ffsll((long long)m) : 0;
 }
 
 // 1 / L_ll for the row of `lane` from the finished diagonal: hardware reciprocal (4.5e-8) + two Newton steps.
@@ -97,14 +102,13 @@ __device__ inline double potrf_dinv(double lll) {
 // by one wave only when the caller's other waves wait at a later barrier, so plain wave-level ordering is used instead.
 template <int LD>
 __device__ inline double potrf_tile_lds(double (*Ls)[LD], int lane, int kb, int* __restrict__ info) {
-    int bad = 0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int c0 = 16 * s;
         double a[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[j] = Ls[lane][c0 + j];      // row `lane`, this slab (rows < c0 carry unused values)
-        potrf_slab(a, c0, bad);
+        potrf_slab(a, c0);
 #pragma unroll
         for (int j = 0; j < 16; ++j) Ls[lane][c0 + j] = a[j];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -119,8 +123,10 @@ __device__ inline double potrf_tile_lds(double (*Ls)[LD], int lane, int kb, int*
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    const double lll = Ls[lane][lane];
+    const int bad = potrf_first_bad(lll);
     if (bad != 0 && lane == 0) atomicCAS(info, 0, kb * 64 + bad);
-    return potrf_dinv(Ls[lane][lane]);
+    return potrf_dinv(lll);
 }
 
 // The same factorisation by a whole 256-thread workgroup: wave 0 runs the slab recurrences, the rank-16 tile updates
@@ -128,7 +134,6 @@ __device__ inline double potrf_tile_lds(double (*Ls)[LD], int lane, int kb, int*
 template <int LD>
 __device__ inline double potrf_tile_lds_wg(double (*Ls)[LD], int tid, int kb, int* __restrict__ info) {
     const int lane = tid & 63, w = tid >> 6;
-    int bad = 0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int c0 = 16 * s;
@@ -136,7 +141,7 @@ __device__ inline double potrf_tile_lds_wg(double (*Ls)[LD], int tid, int kb, in
             double a[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) a[j] = Ls[lane][c0 + j];
-            potrf_slab(a, c0, bad);
+            potrf_slab(a, c0);
 #pragma unroll
             for (int j = 0; j < 16; ++j) Ls[lane][c0 + j] = a[j];
         }
@@ -151,8 +156,11 @@ __device__ inline double potrf_tile_lds_wg(double (*Ls)[LD], int tid, int kb, in
         __syncthreads();
     }
     __syncthreads();
-    if (w == 0 && bad != 0 && lane == 0) atomicCAS(info, 0, kb * 64 + bad);
-    return w == 0 ? potrf_dinv(Ls[lane][lane]) : 1.0;
+    if (w != 0) return 1.0;
+    const double lll = Ls[lane][lane];
+    const int bad = potrf_first_bad(lll);
+    if (bad != 0 && lane == 0) atomicCAS(info, 0, kb * 64 + bad);
+    return potrf_dinv(lll);
 }
 
 // First diagonal block (the later ones are factorised inside syrk_update_kernel by the workgroup that finishes them).
@@ -574,7 +582,6 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
                                                             int* sver) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     kb = __builtin_amdgcn_readfirstlane(kb);
-    int bad = 0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int c0 = 16 * s;
@@ -582,7 +589,7 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
             double a[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) a[j] = ct_T0[lane][c0 + j];
-            potrf_slab(a, c0, bad);
+            potrf_slab(a, c0);
 #pragma unroll
             for (int j = 0; j < 16; ++j) ct_T0[lane][c0 + j] = a[j];
         } else if (w == 3 && s > 0) {                          // slab s - 1 was written out in the previous round: publish it
@@ -613,8 +620,11 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
         __syncthreads();
     }
     __syncthreads();
-    if (w == 0 && bad != 0 && lane == 0) atomicCAS(info, 0, kb * 64 + bad);
-    return w == 0 ? potrf_dinv(ct_T0[lane][lane]) : 1.0;
+    if (w != 0) return 1.0;
+    const double lll = ct_T0[lane][lane];
+    const int bad = potrf_first_bad(lll);
+    if (bad != 0 && lane == 0) atomicCAS(info, 0, kb * 64 + bad);
+    return potrf_dinv(lll);
 }
 // A tile in flight: all 16 loads of a thread are issued before the first one is consumed (several tiles are fetched
 // back to back and only then written to LDS: one memory round trip instead of one per tile)
