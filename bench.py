@@ -461,9 +461,9 @@ def main():
                                                "flops_per_point": N * (2 * d + 3), "counters": pmc_summary("predict_mean_mfma_kernel<")}
             ch_tf = extras["cholesky_gflops"] / 1e3
             extras["roofline_cholesky"] = {"bound": "mfma", "achieved": ch_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": ch_tf / FP64_PEAK_TFLOPS, "kernel": "trsm_panel + syrk_update with fused diagonal potrf (N^3/3 flops)",
-                                           "counters": pmc_summary("syrk_update_kernel", "mean"),
-                                           "note": "N=2000 is latency-bound on the panel critical path; see DESIGN.md for N=10000"}
+                                           "frac": ch_tf / FP64_PEAK_TFLOPS, "kernel": "chol_tasks_kernel (one launch, tile tasks with slab-wise hand-over; N^3/3 flops, assembly included in the time)",
+                                           "counters": pmc_summary("chol_tasks_kernel", "mean"),
+                                           "note": "N=2000 is latency-bound on the chain of 31 diagonal factorisations; N=10000: 30 TFLOP/s, N=16000: 44 TFLOP/s on the panel path (DESIGN.md par. 7, profiles/r02_cholesky_*)"}
             out["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             out["parity_gate"] = parity_gate(cfg, gp, y_dev, cpu_chain, args)
