@@ -15,18 +15,24 @@ __global__ void pingpong(unsigned long long* a, unsigned long long* b, int wgA, 
     unsigned long long* other = me == 0 ? b : a;
     for (int r = 1; r <= rounds; ++r) {
         if (me == 0) {
-            if (MODE == 0) __hip_atomic_store(other, (unsigned long long)r, __ATOMIC_RELAXED, SCOPE);
+            if (MODE == 0 || MODE >= 3) __hip_atomic_store(other, (unsigned long long)r, __ATOMIC_RELAXED, SCOPE);
             else __hip_atomic_exchange(other, (unsigned long long)r, __ATOMIC_RELAXED, SCOPE);
         }
         long long spins = 0;
         while (true) {
-            unsigned long long v = (MODE == 2) ? __hip_atomic_fetch_add(mine, 0ull, __ATOMIC_RELAXED, SCOPE)
-                                               : __hip_atomic_load(mine, __ATOMIC_RELAXED, SCOPE);
+            unsigned long long v;
+            if (MODE == 3) {          // poll through the SCALAR memory path (s_load ... glc: the scalar cache is bypassed)
+                asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(mine) : "memory");
+            } else if (MODE == 4) {   // the same after invalidating the scalar cache
+                asm volatile("s_dcache_inv\n\ts_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(mine) : "memory");
+            } else {
+                v = (MODE == 2) ? __hip_atomic_fetch_add(mine, 0ull, __ATOMIC_RELAXED, SCOPE) : __hip_atomic_load(mine, __ATOMIC_RELAXED, SCOPE);
+            }
             if (v >= (unsigned long long)r) break;
-            if (++spins > 20000000) { *err = 1; return; }
+            if (++spins > (MODE >= 3 ? 2000000 : 20000000)) { *err = 1; return; }
         }
         if (me == 1) {
-            if (MODE == 0) __hip_atomic_store(other, (unsigned long long)r, __ATOMIC_RELAXED, SCOPE);
+            if (MODE == 0 || MODE >= 3) __hip_atomic_store(other, (unsigned long long)r, __ATOMIC_RELAXED, SCOPE);
             else __hip_atomic_exchange(other, (unsigned long long)r, __ATOMIC_RELAXED, SCOPE);
         }
     }
@@ -63,12 +69,15 @@ int main() {
     for (auto& m : mems) {
         if (!m.p) { printf("%s: allocation not supported\n", m.name); continue; }
         for (auto& pl : places) {
-            printf("%-12s %-22s one-way hop us: agent ld/st %.3f | system ld/st %.3f | agent xchg+ld %.3f | agent xchg+rmw-poll %.3f\n",
+            printf("%-12s %-22s one-way hop us: agent ld/st %.3f | system ld/st %.3f | agent xchg+ld %.3f | agent xchg+rmw-poll %.3f | "
+                   "scalar-load poll (glc) %.3f | with s_dcache_inv %.3f   (-1: never seen)\n",
                    m.name, pl.name,
                    run<__HIP_MEMORY_SCOPE_AGENT, 0>(m.p, pl.a, pl.b, rounds, err),
                    run<__HIP_MEMORY_SCOPE_SYSTEM, 0>(m.p, pl.a, pl.b, rounds, err),
                    run<__HIP_MEMORY_SCOPE_AGENT, 1>(m.p, pl.a, pl.b, rounds, err),
-                   run<__HIP_MEMORY_SCOPE_AGENT, 2>(m.p, pl.a, pl.b, rounds, err));
+                   run<__HIP_MEMORY_SCOPE_AGENT, 2>(m.p, pl.a, pl.b, rounds, err),
+                   run<__HIP_MEMORY_SCOPE_AGENT, 3>(m.p, pl.a, pl.b, rounds, err),
+                   run<__HIP_MEMORY_SCOPE_AGENT, 4>(m.p, pl.a, pl.b, rounds, err));
             fflush(stdout);
         }
     }
