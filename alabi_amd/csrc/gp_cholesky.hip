@@ -564,12 +564,16 @@ __shared__ double ct_T1[64][66];
 __shared__ double ct_T2[64][66];                                      // CHAIN: the diagonal tile, parked while the panel tile is solved
 __shared__ double ct_di[64];
 // One 16-column slab of the panel solve (CHAIN: the slabs of L[k-1,k-1] arrive one by one, see ct_potrf_publish).
+// The slab's recurrence for all 64 rows of the tile by ONE wave (lane = row; the instruction stream is the same as for 16
+// rows): the other waves are then free to fetch the next slab of L[kk,kk] meanwhile (solve_by_slabs).
 template <int S>
-__device__ __attribute__((noinline)) void ct_trsm_slab() {
+__device__ __attribute__((noinline)) void ct_trsm_rec() {
+    trsm_slab_row<66>(ct_T0, ct_T1, ct_di, threadIdx.x & 63, 16 * S);
+}
+// The slab's effect on the later slabs: rank-16 updates on the matrix cores, wave w owns rows 16 w .. 16 w + 15.
+template <int S>
+__device__ __attribute__((noinline)) void ct_trsm_upd() {
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    if (lane < 16) trsm_slab_row<66>(ct_T0, ct_T1, ct_di, 16 * w + lane, 16 * S);
-    if (S == 3) return;
-    __syncthreads();
 #pragma unroll
     for (int t = S + 1; t < 4; ++t) tile_update_16<66>(ct_T1, 16 * w, 16 * t, ct_T1, 16 * w, ct_T0, 16 * t, 16 * S, lane);
 }
@@ -658,45 +662,83 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
     // update the later slabs on the matrix cores.  false = a wait ran out (err is set; every thread returns).
     auto solve_by_slabs = [&](int kk) -> bool {
         const double* Lp = A + (size_t)(kk * 64) * ld + kk * 64;
+        // slab 0: wait for it (bounded), every thread fetches its share
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(sver + kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 1) {
+                if (++spins > spin_limit || ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    task_s[4] = ntasks;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        if (task_s[4] >= ntasks) return false;
+        {
+            unsigned long long v[4];
+#pragma unroll
+            for (int e_ = 0; e_ < 4; ++e_) {
+                const int e = tid + 256 * e_;
+                v[e_] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(Lp + (size_t)(e >> 4) * ld + (e & 15)), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid < 16) di[tid] = __longlong_as_double((long long)__hip_atomic_load(
+                              reinterpret_cast<const unsigned long long*>(dinv + kk * 64 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+            for (int e_ = 0; e_ < 4; ++e_) {
+                const int e = tid + 256 * e_;
+                T0[e >> 4][e & 15] = __longlong_as_double((long long)v[e_]);
+            }
+        }
+        __syncthreads();
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
-            if (tid == 0) {
-                int spins = 0;
-                while (__hip_atomic_load(sver + kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sl + 1) {
+            // wave 0 runs the slab's recurrence for all 64 rows; wave 1 meanwhile waits for the NEXT slab of L[kk,kk] and fetches
+            // it (its columns of T0 and its reciprocals have no reader yet): the two memory round trips per slab leave the chain
+            if (w == 0) {
+                if (sl == 0) ct_trsm_rec<0>();
+                else if (sl == 1) ct_trsm_rec<1>();
+                else if (sl == 2) ct_trsm_rec<2>();
+                else ct_trsm_rec<3>();
+            } else if (w == 1 && sl < 3) {
+                const int l1 = tid & 63;
+                int ok = 1, spins = 0;
+                while (__hip_atomic_load(sver + kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sl + 2) {      // wave-uniform
                     if (++spins > spin_limit || ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        task_s[4] = ntasks;
+                        ok = 0;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                if (!ok) {
+                    if (l1 == 0) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); task_s[4] = ntasks; }
+                } else {
+                    unsigned long long v[16];
+#pragma unroll
+                    for (int e_ = 0; e_ < 16; ++e_) {
+                        const int e = l1 + 64 * e_;
+                        v[e_] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(Lp + (size_t)(e >> 4) * ld + 16 * (sl + 1) + (e & 15)),
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (l1 < 16) di[16 * (sl + 1) + l1] = __longlong_as_double((long long)__hip_atomic_load(
+                                     reinterpret_cast<const unsigned long long*>(dinv + kk * 64 + 16 * (sl + 1) + l1), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+                    for (int e_ = 0; e_ < 16; ++e_) {
+                        const int e = l1 + 64 * e_;
+                        T0[e >> 4][16 * (sl + 1) + (e & 15)] = __longlong_as_double((long long)v[e_]);
+                    }
+                }
             }
-            __syncthreads();                                          // also: the previous slab's tile updates are done
+            __syncthreads();                                          // the slab is solved, the next one is in LDS
             if (task_s[4] >= ntasks) return false;
-            {
-                unsigned long long v[4];
-#pragma unroll
-                for (int e_ = 0; e_ < 4; ++e_) {
-                    const int e = tid + 256 * e_;
-                    v[e_] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(Lp + (size_t)(e >> 4) * ld + 16 * sl + (e & 15)),
-                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (tid < 16) di[16 * sl + tid] = __longlong_as_double((long long)__hip_atomic_load(
-                                  reinterpret_cast<const unsigned long long*>(dinv + kk * 64 + 16 * sl + tid), __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_AGENT));
-#pragma unroll
-                for (int e_ = 0; e_ < 4; ++e_) {
-                    const int e = tid + 256 * e_;
-                    T0[e >> 4][16 * sl + (e & 15)] = __longlong_as_double((long long)v[e_]);
-                }
-            }
-            __syncthreads();
-            if (sl == 0) ct_trsm_slab<0>();
-            else if (sl == 1) ct_trsm_slab<1>();
-            else if (sl == 2) ct_trsm_slab<2>();
-            else ct_trsm_slab<3>();
+            if (sl == 0) ct_trsm_upd<0>();
+            else if (sl == 1) ct_trsm_upd<1>();
+            else if (sl == 2) ct_trsm_upd<2>();
+            if (sl < 3) __syncthreads();                              // the later slabs carry this slab's update
         }
-        __syncthreads();
         return true;
     };
     for (;;) {
