@@ -660,7 +660,7 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
     // Panel solve of the tile in T1 against L[kk,kk], consumed slab by slab as its factorisation publishes them (sver[kk] =
     // slabs written through so far): wait (bounded), fetch the slab's 64 x 16 block and its reciprocals, solve the slab,
     // update the later slabs on the matrix cores.  false = a wait ran out (err is set; every thread returns).
-    auto solve_by_slabs = [&](int kk) -> bool {
+    auto solve_by_slabs = [&](int kk, auto&& side) -> bool {   // side(s): run by waves 2 and 3 under the recurrence of slab s + 1, when slab s of the solved tile is final
         const double* Lp = A + (size_t)(kk * 64) * ld + kk * 64;
         // slab 0: wait for it (bounded), every thread fetches its share
         if (tid == 0) {
@@ -731,6 +731,8 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
                         T0[e >> 4][16 * (sl + 1) + (e & 15)] = __longlong_as_double((long long)v[e_]);
                     }
                 }
+            } else if (w >= 2 && sl >= 1) {
+                side(sl - 1);
             }
             __syncthreads();                                          // the slab is solved, the next one is in LDS
             if (task_s[4] >= ntasks) return false;
@@ -825,7 +827,7 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
                 tile_fetch(rb, A + (size_t)(ti * 64) * ld + tk * 64, ld, tid);
                 tile_put(T1, rb, tid);
             }
-            if (!solve_by_slabs(tk)) return;
+            if (!solve_by_slabs(tk, [](int) {})) return;
             tile_store_sc1(A + (size_t)(ti * 64) * ld + tk * 64, ld, T1, tid, false);
             publish_version(ver + ti * nb + tk, tk + 1, tid);
         } else {
@@ -846,43 +848,51 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
 #ifdef ALABI_CHOL_PROF
                 p1 = __builtin_amdgcn_s_memrealtime();
 #endif
+                // tile (k,k) -= X X^T (lower triangle: ten 16 x 16 tiles) is accumulated by waves 2 and 3 -- idle while wave 0 runs a
+                // slab's recurrence and wave 1 fetches the next slab -- one solved slab of X behind the solve; only the last slab's
+                // share follows it.   w2: (0,0) (1,0) (1,1) (2,0) (2,1)    w3: (2,2) (3,0) (3,1) (3,2) (3,3)
+                v4f64 dacc[5];
+                auto dtile = [&](int j, int& rt, int& ct) {
+                    if (w == 2) { rt = j == 0 ? 0 : j < 3 ? 1 : 2; ct = j == 0 ? 0 : j == 1 ? 0 : j == 2 ? 1 : j == 3 ? 0 : 1; }
+                    else { rt = j == 0 ? 2 : 3; ct = j == 0 ? 2 : j - 1; }
+                };
+                auto diag_update = [&](int sl) {
+                    if (sl == 0) {
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) {
+                            int rt, ct; dtile(j, rt, ct);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) dacc[j][i] = T2[16 * rt + lk + 4 * i][16 * ct + lr];
+                        }
+                    }
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) {
+                        const int ks = 4 * sl + kq;
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) {
+                            int rt, ct; dtile(j, rt, ct);
+                            dacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-T1[16 * rt + lr][4 * ks + lk], T1[16 * ct + lr][4 * ks + lk], dacc[j], 0, 0, 0);
+                        }
+                    }
+                };
                 // the panel solve, slab by slab as CHAIN(k-1) publishes the slabs of L[k-1,k-1] (bounded wait each)
-                if (!solve_by_slabs(tk - 1)) return;
-                __syncthreads();
+                if (!solve_by_slabs(tk - 1, diag_update)) return;
 #ifdef ALABI_CHOL_PROF
                 p2 = __builtin_amdgcn_s_memrealtime();
 #endif
                 tile_store_sc1(A + (size_t)(tk * 64) * ld + (tk - 1) * 64, ld, T1, tid, false);
+                if (w >= 2) diag_update(3);                              // while the stores drain
                 publish_version(ver + tk * nb + (tk - 1), tk, tid);      // the solved panel tile is final: updates of column k can start
 #ifdef ALABI_CHOL_PROF
                 p3 = __builtin_amdgcn_s_memrealtime();
 #endif
-                // tile (k,k) -= X X^T, lower triangle only: its ten 16 x 16 tiles dealt 3 / 3 / 2 / 2 to the waves
-                //   w0: (0,0) (3,0) (3,1)   w1: (1,0) (1,1) (3,2)   w2: (2,0) (2,1)   w3: (2,2) (3,3)
-                const int nt = w < 2 ? 3 : 2;
-                const int rt0 = w == 0 ? 0 : w == 1 ? 1 : 2, ct0 = w == 3 ? 2 : 0;
-                const int rt1 = w == 0 ? 3 : w == 1 ? 1 : w == 2 ? 2 : 3, ct1 = w == 0 ? 0 : w == 3 ? 3 : 1;
-                const int rt2 = 3, ct2 = w == 0 ? 1 : 2;                // waves 0 and 1 only
-                v4f64 acc0, acc1, acc2 = {0.0, 0.0, 0.0, 0.0};
+                if (w >= 2) {                                            // (the barrier inside publish_version: everyone is done with T0)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc0[i] = T2[16 * rt0 + lk + 4 * i][16 * ct0 + lr];
-                    acc1[i] = T2[16 * rt1 + lk + 4 * i][16 * ct1 + lr];
-                    if (nt == 3) acc2[i] = T2[16 * rt2 + lk + 4 * i][16 * ct2 + lr];
-                }
+                    for (int j = 0; j < 5; ++j) {
+                        int rt, ct; dtile(j, rt, ct);
 #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-T1[16 * rt0 + lr][4 * ks + lk], T1[16 * ct0 + lr][4 * ks + lk], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-T1[16 * rt1 + lr][4 * ks + lk], T1[16 * ct1 + lr][4 * ks + lk], acc1, 0, 0, 0);
-                    if (nt == 3)
-                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-T1[16 * rt2 + lr][4 * ks + lk], T1[16 * ct2 + lr][4 * ks + lk], acc2, 0, 0, 0);
-                }
-                __syncthreads();                                      // everyone is done reading T0 (L[k-1,k-1])
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    T0[16 * rt0 + lk + 4 * i][16 * ct0 + lr] = acc0[i];
-                    T0[16 * rt1 + lk + 4 * i][16 * ct1 + lr] = acc1[i];
-                    if (nt == 3) T0[16 * rt2 + lk + 4 * i][16 * ct2 + lr] = acc2[i];
+                        for (int i = 0; i < 4; ++i) T0[16 * rt + lk + 4 * i][16 * ct + lr] = dacc[j][i];
+                    }
                 }
             } else {
                 tile_load_sc1(T0, D, ld, tid);
