@@ -497,7 +497,7 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Task-queue factorisation for up to 64 block columns (N <= 4096): ONE launch instead of 2 nb - 1.
+// Task-queue factorisation for up to 128 block columns (default for N = 961..5376): ONE launch instead of 2 nb - 1.
 // The launch-per-step path above is a chain of dependent kernels: per block column a panel solve (11 us) and an update with
 // the next diagonal factorisation fused in (19.6 us), each behind a kernel boundary -- 1.02 ms at N = 2000 for 2.67 GFLOP.
 // Here the same 64 x 64 tile operations are TASKS in a static topological order; persistent workgroups draw the next task
@@ -960,19 +960,17 @@ static int chol_task_list(int nb, const CholTask** dev, int* count) {
 int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
     *launched = 0;
     const int ld = gp->Npad, nb = gp->Npad / 64;
-    // Default for 16..64 block columns (N = 961..4096; ALABI_CHOL_TASKS=0 / 1 forces it off / on for 3..64).  Measured
-    // (tools/prof_cholesky.py, assembly included): N = 1024 0.40 vs 0.48 ms launch-per-step, 2000 0.73 vs 0.93, 3072 1.24 vs
-    // 1.45, 4096 1.97 vs 2.11; below 1024 the two are equal.  Per block column the chain task spends ~2 us fetching its three
-    // tiles, ~8 us in the panel solve, 2.5 us in the diagonal update, ~10 us in the 64-pivot factorisation and 2 us
-    // publishing (-DALABI_CHOL_PROF): the two serial recurrences are most of it, the launch boundaries this design removes
-    // were ~3 us per column.
+    // Default for 16..84 block columns (N = 961..5376; ALABI_CHOL_TASKS=0 / 1 forces it off / on for 3..128).  Measured
+    // (tools/prof_cholesky.py, assembly included): N = 1024 0.34 vs 0.46 ms launch-per-step, 2000 0.60-0.64 vs 0.93, 3072 1.03
+    // vs 1.38, 4096 1.7 vs 2.06, 5000 2.71 vs 2.91, 6000 4.08 vs 4.00 (from there on the 64 x 64 rank-64 updates of the bulk
+    // dominate and the launch-per-step kernels, then the panel path, are ahead); below 1024 the two are equal.
     const char* env = getenv("ALABI_CHOL_TASKS");
     const bool forced_on = env && env[0] == '1', forced_off = env && env[0] == '0';
-    if (nb < 3 || nb > 64 || forced_off || (!forced_on && nb < 16)) return ALABI_OK;
+    if (nb < 3 || nb > 128 || forced_off || (!forced_on && (nb < 16 || nb > 84))) return ALABI_OK;
     const size_t ctl_ints = 2 + (size_t)nb * nb + nb + 66;             // + 66: alignment + phase timers of an ALABI_CHOL_PROF build
     if (gp->chol_ctl_ints < ctl_ints) {
         if (gp->chol_ctl) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); ALABI_HIP_CHECK(hipFree(gp->chol_ctl)); gp->chol_ctl = nullptr; }
-        const size_t cap_nb = gp->n_cap / 64 < 64 ? gp->n_cap / 64 : 64;
+        const size_t cap_nb = gp->n_cap / 64 < 128 ? gp->n_cap / 64 : 128;
         const size_t cap = 2 + 66 + cap_nb * cap_nb + cap_nb;
         ALABI_HIP_CHECK(hipMalloc(&gp->chol_ctl, (cap > ctl_ints ? cap : ctl_ints) * sizeof(int)));
         gp->chol_ctl_ints = cap > ctl_ints ? cap : ctl_ints;

@@ -599,7 +599,7 @@ def test_cholesky_panel_path(torch_gpu, monkeypatch, N, panel):
     assert np.max(np.abs(facs["panel"][2][1] - facs["rank64"][2][1])) <= 1e-8 * np.exp(h["log_amp"])
 
 
-@pytest.mark.parametrize("N", [130, 200, 705, 2000, 4096])
+@pytest.mark.parametrize("N", [130, 200, 705, 2000, 4096, 5200])
 def test_cholesky_task_queue(torch_gpu, monkeypatch, N):
     """Up to 64 block columns the factorisation is ONE launch: persistent workgroups draw tile tasks (chain / panel solve /
     update) from a queue and hand tiles over through versioned write-through stores.  Same factor as the launch-per-step path
