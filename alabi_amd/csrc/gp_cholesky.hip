@@ -1011,7 +1011,7 @@ int launch_cholesky(alabi_gp* gp, hipStream_t s) {
     // the panel path wins from about N = 8000 on (N = 10000: 14.3 -> 11.3 ms, N = 16000: 49.6 -> 31.4 ms with panels of 8;
     // panels of 4: 11.8 / 33.0 ms); below that the extra launches per panel cost more than the trailing traffic they save
     // (N = 5000: 3.2 vs 3.9 ms).
-    int panel = nb >= 128 ? 8 : 0;
+    int panel = nb >= 110 ? 8 : 0;                          // N >= 7040 (N = 7000: 5.33 vs 5.54 ms rank-64, 7500: 6.05 vs 6.59; 6500: 4.80 vs 4.73)
     if (const char* env = getenv("ALABI_CHOL_PANEL")) { const int v = atoi(env); if (v == 0 || v == 2 || v == 4 || v == 6 || v == 8) panel = v; }
     if (panel == 0) {
         for (int kb = 0; kb + 1 < nb; ++kb) {

@@ -12,7 +12,7 @@ for N in sizes:
     X = rng.uniform(-3, 3, (N, d))
     log_M = np.log(np.full(d, 30.0 if d == 10 else 60.0))
     variants = [("task queue (one launch)", "0", "1", "1")] if N <= 8192 else []
-    variants += [("rank-64", "0", "1", "0"), ("panel-4 serial", "4", "0", "0"), ("panel-4 look-ahead", "4", "1", "0"), ("panel-2 look-ahead", "2", "1", "0")] + ([("panel-6 look-ahead", "6", "1", "0"), ("panel-8 look-ahead", "8", "1", "0")] if N >= 8000 else [])
+    variants += [("rank-64", "0", "1", "0"), ("panel-4 serial", "4", "0", "0"), ("panel-4 look-ahead", "4", "1", "0"), ("panel-2 look-ahead", "2", "1", "0")] + ([("panel-6 look-ahead", "6", "1", "0"), ("panel-8 look-ahead", "8", "1", "0")] if N >= 5500 else [])
     for tag, panel, la, tq in variants:
         os.environ["ALABI_CHOL_PANEL"] = panel; os.environ["ALABI_CHOL_LOOKAHEAD"] = la; os.environ["ALABI_CHOL_TASKS"] = tq
         gp = HipGP(d, 0.0, -12.0, 0.0, log_M)
