@@ -1303,6 +1303,9 @@ int launch_ens_half_args(alabi_ens* e, const HalfArgs& args_in, int nblocks, hip
     int np = 1;
     if (threads <= 512 && db <= 24 && !(env && env[0] == '0')) {
         if (total > 3LL * n_cu && db <= 16) np = 4; else if (total > n_cu) np = 2;   // q[NP][D] lives in registers
+        if (env && env[0] == '4' && db <= 16) np = 4;
+        if (env && env[0] == '2') np = 2;
+        if (env && env[0] == '1') np = 1;
     }
     if (np == 4) {
         ALABI_STREAM_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(e->gp->kf.type, hipLaunchKernelGGL((ens_half_multi_kernel<D, GENERIC, 4>),
