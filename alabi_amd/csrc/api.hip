@@ -134,6 +134,7 @@ int alabi_gp_destroy(alabi_gp* gp) {
     if (gp->L) (void)hipFree(gp->L);
     if (gp->Xt) (void)hipFree(gp->Xt);
     if (gp->Xa) (void)hipFree(gp->Xa);
+    if (gp->xa_centre) (void)hipFree(gp->xa_centre);
     if (gp->y) (void)hipFree(gp->y);
     if (gp->alpha) (void)hipFree(gp->alpha);
     if (gp->dinv) (void)hipFree(gp->dinv);
@@ -526,6 +527,7 @@ int alabi_ens_destroy(alabi_ens* e) {
     if (e->consts) (void)hipFree(e->consts);
     if (e->hist) (void)hipFree(e->hist);
     if (e->prop) (void)hipFree(e->prop);
+    if (e->part) (void)hipFree(e->part);
     if (e->err) (void)hipFree(e->err);
     delete e;
     return ALABI_OK;
@@ -663,14 +665,23 @@ int alabi_ens_run(alabi_ens* e, double* coords, double* logp, long long step0, l
     // Persistent dataflow path: training set pinned in registers (Npad <= 2048: 256 compute lanes x up to 4 point pairs), one
     // workgroup per list position.  It synchronises at the end to read the time-out flag.
     e->last_path = 0;
-    if (e->stream_ok && s != nullptr && ens_stream_fits(e)) {
-        e->last_path = 1;
+    // Which persistent kernel: ens_stream_kernel where the training set fits one workgroup's registers (N <= 2048, small d),
+    // ens_group_kernel (training set partitioned over groups of workgroups, matrix-core kernel sums) beyond that;
+    // ALABI_ENS_GROUP=0 disables the latter, =1 prefers it wherever its blocking is feasible.
+    const char* genv = getenv("ALABI_ENS_GROUP");
+    const bool group_off = genv && genv[0] == '0', group_pref = genv && genv[0] == '1';
+    const bool can_stream = ens_stream_fits(e);
+    const bool use_group = e->stream_ok && s != nullptr && !group_off && (group_pref || !can_stream) && ens_group_fits(e);
+    if (e->stream_ok && s != nullptr && (can_stream || use_group)) {
+        e->last_path = use_group ? 3 : 1;
         ALABI_HIP_CHECK(hipMemsetAsync(e->err, 0, sizeof(int), s));
         long long remaining = nsteps;
         while (remaining > 0) {
             const int K = (int)(remaining < e->chunk_cap ? remaining : e->chunk_cap);
             if ((st = launch_ens_draw(e, K, a, s)) != ALABI_OK) return st;
-            if ((st = launch_ens_stream(e, coords, logp, K, thin_by, chain, chain_logp, n_accept, s)) != ALABI_OK) return st;
+            if (use_group) st = launch_ens_group(e, coords, logp, K, thin_by, chain, chain_logp, n_accept, s);
+            else st = launch_ens_stream(e, coords, logp, K, thin_by, chain, chain_logp, n_accept, s);
+            if (st != ALABI_OK) return st;
             if ((st = launch_ens_advance(e, K, s)) != ALABI_OK) return st;
             remaining -= K;
         }

@@ -67,6 +67,7 @@ struct alabi_gp {
     double* Xt = nullptr;     // [d, n_cap]  scaled, transposed training inputs (SoA)
     double* Xa = nullptr;     // [round_up(d + 2, 4), n_cap] augmented rows (Xt, -|x|^2 / 2, 1, 0..) for the matrix-core predict-mean kernel
     long long xa_gen = -1;    // factor_gen the rows belong to (built lazily)
+    double* xa_centre = nullptr;   // [ALABI_MAX_DIM] mean of the scaled training inputs: Xa rows and the query operands are taken relative to it
     double* y = nullptr;      // [n_cap]
     double* alpha = nullptr;  // [n_cap]
     double* dinv = nullptr;   // [n_cap] 1 / L_ii (every triangular solve multiplies by it)
@@ -146,6 +147,10 @@ struct alabi_ens {
     int last_path = 0;                   // 1 persistent kernel, 2 its speculative variant, 0 one launch per half step
     int stream_ok = 0;                   // eligible: training set fits the lanes' registers, one workgroup per CU
     int spec_ok = 0;                     // W * E workgroups fit one per CU: the speculative persistent kernel (ens_spec_kernel)
+    // group kernel (ens_group_kernel: training set partitioned over the members of a group, proposals streamed through)
+    unsigned long long* part = nullptr;  // [2 chunk_cap][E][NG][G][16 Q] partial kernel sums (allocated on first use)
+    size_t part_words = 0;
+    int group_q = 0, group_g = 0, group_ng = 0;   // blocking of the last group-kernel launch
 };
 
 namespace alabi {
@@ -162,6 +167,7 @@ int launch_alpha(alabi_gp* gp, hipStream_t s);
 int launch_reductions(alabi_gp* gp, hipStream_t s);
 // gp_predict.hip
 int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu, hipStream_t s);
+int ensure_xa(alabi_gp* gp, hipStream_t s);           // augmented, centred rows Xa of the current factor (matrix-core predict-mean, group ensemble kernel)
 // Process-wide cache of the large scratch buffers (variance workspace, cached L^-1): the reference creates a new GP object
 // for every refit (gp_utils.py:233), and a 1-2 GiB hipMalloc per new handle costs tens of milliseconds.
 void* dev_cache_take(size_t need, size_t* bytes);   // a cached buffer of at least `need` bytes, or nullptr
@@ -216,4 +222,11 @@ int launch_ens_advance(alabi_ens* e, long long n, hipStream_t s);
 bool ens_stream_fits(const alabi_ens* e);
 int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
                       long long* n_accept, hipStream_t s);
+// ens_group.hip
+bool ens_group_fits(const alabi_ens* e);
+int launch_ens_group(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
+                     long long* n_accept, hipStream_t s);
+int launch_ens_hist_prologue(alabi_ens* e, double* coords, double* logp, int K, hipStream_t s);
+int launch_ens_hist_epilogue(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
+                             long long* n_accept, hipStream_t s);
 }  // namespace alabi

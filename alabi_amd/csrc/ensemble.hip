@@ -1182,13 +1182,34 @@ bool ens_stream_fits(const alabi_ens* e) { return ens_stream_ppt(e) > 0; }
             hipLaunchKernelGGL((ens_stream_kernel<D, PPT_, TMAX_, GENERIC>), dim3(e->stream_grid, e->E), dim3(T + 128), 0, s, a))) \
     }
 
+// Version history around a persistent launch of K steps: rows 1..K <- sentinel, row 0 <- (coords, logp) before it;
+// (coords, logp) <- row K, chain / counters <- rows 1..K after it.  Shared by ens_stream_kernel and ens_group_kernel.
+int launch_ens_hist_prologue(alabi_ens* e, double* coords, double* logp, int K, hipStream_t s) {
+    const int WT = e->W * e->E, row = e->d + 2;
+    hipLaunchKernelGGL(ens_hist_fill_kernel, dim3(1024), dim3(256), 0, s, e->hist + (size_t)WT * row, (size_t)K * WT * row);
+    hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp, e->hist, WT, e->d, 1);
+    ALABI_LAUNCH_CHECK();
+    return ALABI_OK;
+}
+
+int launch_ens_hist_epilogue(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
+                             long long* n_accept, hipStream_t s) {
+    const int WT = e->W * e->E, row = e->d + 2;
+    hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp,
+                       e->hist + (size_t)K * WT * row, WT, e->d, 0);
+    if (chain || chain_logp || n_accept)
+        hipLaunchKernelGGL(ens_hist_chain_kernel, dim3(2048), dim3(256), 0, s, e->hist, K, WT, e->d, thin_by, e->run_state,
+                           e->err, chain, chain_logp, reinterpret_cast<unsigned long long*>(n_accept));
+    ALABI_LAUNCH_CHECK();
+    return ALABI_OK;
+}
+
 int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
                       long long* n_accept, hipStream_t s) {
     alabi_gp* gp = e->gp;
-    const int WT = e->W * e->E, row = e->d + 2;
+    const int WT = e->W * e->E;
     const int n0 = (e->W + 1) / 2;
-    hipLaunchKernelGGL(ens_hist_fill_kernel, dim3(1024), dim3(256), 0, s, e->hist + (size_t)WT * row, (size_t)K * WT * row);
-    hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp, e->hist, WT, e->d, 1);
+    { const int st0 = launch_ens_hist_prologue(e, coords, logp, K, s); if (st0 != ALABI_OK) return st0; }
     StreamArgs a{};
     a.hist = e->hist; a.err = e->err; a.rec = e->draws; a.consts = e->consts;
     a.Xt = gp->Xt; a.alpha = gp->alpha; a.chain = chain; a.chain_logp = chain_logp;
@@ -1260,13 +1281,8 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
                 (double)tot[4] / tot[0]);
         fprintf(stderr, "[ens_spec_kernel] finished on the proposal slot: %.3f of the items\n", (double)h_prop_fin / tot[0]);
     }
-    hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp,
-                       e->hist + (size_t)K * WT * row, WT, e->d, 0);
-    if (chain || chain_logp || n_accept)
-        hipLaunchKernelGGL(ens_hist_chain_kernel, dim3(2048), dim3(256), 0, s, e->hist, K, WT, e->d, thin_by, e->run_state,
-                           e->err, chain, chain_logp, reinterpret_cast<unsigned long long*>(n_accept));
     ALABI_LAUNCH_CHECK();
-    return ALABI_OK;
+    return launch_ens_hist_epilogue(e, coords, logp, K, thin_by, chain, chain_logp, n_accept, s);
 }
 
 int launch_ens_draw(alabi_ens* e, int nsteps, double a, hipStream_t s) {

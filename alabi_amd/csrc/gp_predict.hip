@@ -873,13 +873,27 @@ static int ensure_mupart(alabi_gp* gp, size_t bytes, hipStream_t s);
 // the two pipes run side by side.  One wavefront owns 64 queries (four 16-row A operands kept in registers) and walks over
 // the training points 16 at a time (B operand and alpha: one double per lane per k-step, L2-resident); a lane ends with
 // the partial sums of 16 queries over its point column, folded across the 16 lanes of its row with DPP adds.
+// Centre of the scaled training inputs, one workgroup per dimension: r2 is translation invariant, and the augmented dot
+// product q'.x' = q.x - |x|^2/2 - |q|^2/2 loses eps * (|x|^2 + |q|^2) / 2 absolutely, so both sides are taken relative to the
+// training mean (inputs that sit thousands of length scales from the origin would otherwise cost digits of the exponent).
 __global__ void __launch_bounds__(256)
-build_xa_kernel(const double* __restrict__ Xt, int Npad, int d, int rows, double* __restrict__ Xa) {
+xa_centre_kernel(const double* __restrict__ Xt, int Npad, int N, double* __restrict__ centre) {
+    __shared__ double scratch[16];
+    const int k = blockIdx.x;
+    double t = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) t += Xt[(size_t)k * Npad + n];
+    t = block_sum(t, scratch);
+    if (threadIdx.x == 0) centre[k] = t / (double)N;
+}
+
+__global__ void __launch_bounds__(256)
+build_xa_kernel(const double* __restrict__ Xt, int Npad, int d, int rows, const double* __restrict__ centre,
+                double* __restrict__ Xa) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= Npad) return;
     double xx = 0.0;
     for (int k = 0; k < d; ++k) {
-        const double v = Xt[(size_t)k * Npad + n];
+        const double v = Xt[(size_t)k * Npad + n] - centre[k];
         Xa[(size_t)k * Npad + n] = v;
         xx = fma(v, v, xx);
     }
@@ -891,8 +905,8 @@ build_xa_kernel(const double* __restrict__ Xt, int Npad, int d, int rows, double
 template <int KS, bool GENERIC>
 __global__ void __launch_bounds__(256)
 predict_mean_mfma_kernel(const double* __restrict__ Xa, const double* __restrict__ alpha, int Npad,
-                         const double* __restrict__ Xs, int d, long long M, DimVec inv_len, double amp, double mean,
-                         KernelFn kf, double* __restrict__ mu) {
+                         const double* __restrict__ Xs, int d, long long M, DimVec inv_len, const double* __restrict__ centre,
+                         double amp, double mean, KernelFn kf, double* __restrict__ mu) {
     __shared__ double etab[64];                                  // 2^(j/64) for exp2s_tab64
     if (threadIdx.x < 64) etab[threadIdx.x] = exp2((double)threadIdx.x * 0.015625);
     __syncthreads();
@@ -902,7 +916,8 @@ predict_mean_mfma_kernel(const double* __restrict__ Xa, const double* __restrict
     const int lr = lane & 15, lk = lane >> 4;
     const long long q0 = ((long long)blockIdx.x * 4 + wv) * 64;
     if (q0 >= M) return;
-    // A operands: query row lr of tile qt, coordinate 4 s + lk of k-step s (the augmented row q' = (q / l, 1, -|q / l|^2 / 2))
+    // A operands: query row lr of tile qt, coordinate 4 s + lk of k-step s (the augmented row q' = (q / l - c, 1, -|q / l - c|^2 / 2),
+    // c = centre of the scaled training inputs, the same shift build_xa_kernel applied to the rows of Xa)
     double a[4][KS];
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
@@ -910,14 +925,14 @@ predict_mean_mfma_kernel(const double* __restrict__ Xa, const double* __restrict
         const bool valid = m < M;
         double qq = 0.0;
         for (int k = 0; k < d; ++k) {
-            const double v = valid ? Xs[m * d + k] * inv_len.v[k] : 0.0;
+            const double v = valid ? Xs[m * d + k] * inv_len.v[k] - centre[k] : 0.0;
             qq = fma(v, v, qq);
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int c = 4 * s + lk;
             double v = 0.0;
-            if (valid) v = (c < d) ? Xs[m * d + c] * inv_len.v[c] : (c == d) ? 1.0 : (c == d + 1) ? -0.5 * qq : 0.0;
+            if (valid) v = (c < d) ? Xs[m * d + c] * inv_len.v[c] - centre[c] : (c == d) ? 1.0 : (c == d + 1) ? -0.5 * qq : 0.0;
             a[qt][s] = v * qs;
         }
     }
@@ -959,11 +974,15 @@ predict_mean_mfma_kernel(const double* __restrict__ Xa, const double* __restrict
         }
 }
 
-static int ensure_xa(alabi_gp* gp, hipStream_t s) {
+int ensure_xa(alabi_gp* gp, hipStream_t s) {
     const int rows = round_up(gp->d + 2, 4);
     if (!gp->Xa) ALABI_HIP_CHECK(hipMalloc(&gp->Xa, (size_t)rows * gp->n_cap * sizeof(double)));
+    if (!gp->xa_centre) ALABI_HIP_CHECK(hipMalloc(&gp->xa_centre, ALABI_MAX_DIM * sizeof(double)));
     if (gp->xa_gen != gp->factor_gen) {
-        hipLaunchKernelGGL(build_xa_kernel, dim3((gp->Npad + 255) / 256), dim3(256), 0, s, gp->Xt, gp->Npad, gp->d, rows, gp->Xa);
+        hipLaunchKernelGGL(xa_centre_kernel, dim3(gp->d), dim3(256), 0, s, gp->Xt, gp->Npad, gp->N, gp->xa_centre);
+        hipLaunchKernelGGL(build_xa_kernel, dim3((gp->Npad + 255) / 256), dim3(256), 0, s, gp->Xt, gp->Npad, gp->d, rows,
+                           gp->xa_centre, gp->Xa);
+        ALABI_LAUNCH_CHECK();
         gp->xa_gen = gp->factor_gen;
     }
     return ALABI_OK;
@@ -995,7 +1014,7 @@ int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu,
         const long long wgs = (M + 255) / 256;
         if (wgs > 0x7fffffffLL) return ALABI_BAD_ARGUMENT;
         ALABI_DISPATCH_KS(ks, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_mean_mfma_kernel<KS, GENERIC>), dim3((unsigned)wgs),
-            dim3(256), 0, s, gp->Xa, gp->alpha, gp->Npad, Xs, gp->d, M, gp->inv_len, amp, gp->mean, gp->kf, mu)));
+            dim3(256), 0, s, gp->Xa, gp->alpha, gp->Npad, Xs, gp->d, M, gp->inv_len, gp->xa_centre, amp, gp->mean, gp->kf, mu)));
         ALABI_LAUNCH_CHECK();
         return ALABI_OK;
     }
