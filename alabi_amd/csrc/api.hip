@@ -432,13 +432,15 @@ static void free_draws(DrawBuffers& b) {
     if (b.u_z) (void)hipFree(b.u_z);
     if (b.u_acc) (void)hipFree(b.u_acc);
     if (b.packed) (void)hipFree(b.packed);
+    if (b.pos_of) (void)hipFree(b.pos_of);
+    if (b.link) (void)hipFree(b.link);
     b = DrawBuffers{};
 }
 
 static DrawBuffers offset_draws(const DrawBuffers& b, size_t off) {
     DrawBuffers r = b;
     r.order += off; r.cw += off; r.zz += off; r.lnfac += off; r.lnu += off;
-    r.partner += off; r.u_z += off; r.u_acc += off; r.packed += 4 * off;
+    r.partner += off; r.u_z += off; r.u_acc += off; r.packed += 4 * off; r.pos_of += off; r.link += off;
     return r;
 }
 
@@ -480,6 +482,8 @@ int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* 
     if (err == hipSuccess) err = hipMalloc(&b.u_z, n * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&b.u_acc, n * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&b.packed, 4 * n * sizeof(unsigned long long));
+    if (err == hipSuccess) err = hipMalloc(&b.pos_of, n * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&b.link, n * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMalloc(&e->run_state, 4 * sizeof(long long));
     if (err == hipSuccess) err = hipMalloc(&e->consts, 5 * ALABI_MAX_DIM * sizeof(double));
     // persistent dataflow path: one workgroup per list position, all co-resident (at most one per CU)
@@ -528,6 +532,7 @@ int alabi_ens_destroy(alabi_ens* e) {
     if (e->hist) (void)hipFree(e->hist);
     if (e->prop) (void)hipFree(e->prop);
     if (e->part) (void)hipFree(e->part);
+    if (e->cand) (void)hipFree(e->cand);
     if (e->err) (void)hipFree(e->err);
     delete e;
     return ALABI_OK;

@@ -109,6 +109,8 @@ struct DrawBuffers {
     double* u_z;     // raw uniforms (by list position)
     double* u_acc;
     unsigned long long* packed;   // 4 words per list position: walker | partner << 32, zz, lnfac, lnu (persistent kernel)
+    int* pos_of;     // list position (0..W-1 within the ensemble) of every walker, keyed by global walker id (inverse of `order`)
+    unsigned long long* link;     // group kernel: per list position, where the two rows the proposal reads were produced (ens_link_kernel)
 };
 }  // namespace alabi
 
@@ -150,6 +152,8 @@ struct alabi_ens {
     // group kernel (ens_group_kernel: training set partitioned over the members of a group, proposals streamed through)
     unsigned long long* part = nullptr;  // [2 chunk_cap][E][NG][G][16 Q] partial kernel sums (allocated on first use)
     size_t part_words = 0;
+    unsigned long long* cand = nullptr;  // [2 chunk_cap][E][n0][2 d + 4] candidate rows (proposal, old coordinates, logp, ln factors, prior)
+    size_t cand_words = 0;
     int group_q = 0, group_g = 0, group_ng = 0;   // blocking of the last group-kernel launch
 };
 
@@ -226,7 +230,7 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
 bool ens_group_fits(const alabi_ens* e);
 int launch_ens_group(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
                      long long* n_accept, hipStream_t s);
-int launch_ens_hist_prologue(alabi_ens* e, double* coords, double* logp, int K, hipStream_t s);
+int launch_ens_hist_prologue(alabi_ens* e, double* coords, double* logp, int K, bool fill, hipStream_t s);
 int launch_ens_hist_epilogue(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
                              long long* n_accept, hipStream_t s);
 }  // namespace alabi

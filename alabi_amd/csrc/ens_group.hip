@@ -8,27 +8,32 @@
 //     keeps slice m of the (augmented, centred) training rows Xa in LDS for the whole launch (S = Npad / G points, laid out
 //     as ready-made B operands of v_mfma_f64_16x16x4);
 //   * the proposals MOVE: group g owns list positions [g QP, (g+1) QP) of every half step (QP = 16 Q, Q query tiles).  All
-//     its members poll the 2 QP walker rows those proposals read, form the QP proposals (bit-identical arithmetic to the
-//     other paths), and evaluate their kernel sums over their own slice on the matrix cores: the exponent -r^2/2 is ONE
-//     augmented dot product q'.x' (q' = (q/l - c, 1, -|q/l - c|^2/2), x' = (x/l - c, -|x/l - c|^2/2, 1)), the vector unit
-//     only runs the table exp and the alpha FMA (11 instead of 41 fp64 instructions per kernel evaluation);
-//   * the G partial sums of a proposal travel through memory exactly like the walker rows do: one aligned 8-byte sc1 store
-//     per word over a sentinel NaN, polled with sc1 loads -- the data is the flag (cdna_hip_programming.md Guideline 16,
-//     form R2); member m adds the G partials of proposals m, m + G, ... in a FIXED order (j = 0 .. G-1), does their accept
-//     tests and publishes the new walker rows in the same version history the other persistent kernel uses.
+//     its members form the QP proposals (bit-identical arithmetic to the other paths) and evaluate their kernel sums over
+//     their own slice on the matrix cores: the exponent -r^2/2 is ONE augmented dot product q'.x'
+//     (q' = (q/l - c, 1, -|q/l - c|^2/2), x' = (x/l - c, -|x/l - c|^2/2, 1)), the vector unit only runs the table exp and
+//     the alpha FMA (11 instead of 41 fp64 instructions per kernel evaluation);
+//   * ONE memory hop per half step.  A member publishes two things, each word by one aligned 8-byte sc1 store over a
+//     sentinel NaN that the readers poll with sc1 loads (the data is the flag: cdna_hip_programming.md Guideline 16, form
+//     R2): before its kernel sums the CANDIDATE of every proposal it is responsible for (proposal, old coordinates, old
+//     log-probability, (d-1) ln z, ln u', prior term: everything the accept test needs except the kernel sum), after them
+//     its PARTIAL sums.  Nobody waits for an accept decision: whoever needs the row of a walker reads the candidate of the
+//     proposal that produced it plus its G partials, adds them in a FIXED order (j = 0 .. G-1) and repeats the accept test
+//     -- the same bits in every reader.  Which proposal produced which row follows from the draws alone (ens_link_kernel,
+//     before the launch).  The version history `hist` (the chain) is written off the dependency chain with plain stores,
+//     by the group that reads a walker's row as its own one step later, and for the last step by a tail pass.
 //
-// There is no grid-wide barrier: a workgroup waits only for the rows / partials it reads, every dependency points to an
-// earlier half step (or to the same half step's partials, which depend on earlier rows only), so with all workgroups
-// resident (at most one per CU) the oldest unfinished half step can always complete.  Every spin is bounded; on a time-out
-// the launch sets *err, every workgroup leaves and alabi_ens_run repeats the chunk on the launch-per-half-step path.
+// There is no grid-wide barrier: a workgroup waits only for the words it reads, every dependency points to an earlier
+// half step, so with all workgroups resident (at most one per CU) the oldest unfinished half step can always complete.
+// Every spin is bounded; on a time-out the launch sets *err, every workgroup leaves and alabi_ens_run repeats the chunk on
+// the launch-per-half-step path.
 //
 // Summation order differs from the other paths (tiles of 16 points per wave, waves, members), so chains agree with them
 // and with the oracle to rounding (tests: chain <= 1e-7 over hundreds of steps, identical acceptance counts), not bit for
 // bit; they are reproducible run to run for a given (W, N, d, #CUs).
 //
-// Per half step the dependency chain is: rows visible (hop) -> proposals -> kernel sums -> partials visible (hop) ->
-// accept -> row stores.  Work per half step at C4: 512 x 5000 kernel evaluations = 40 tile products per workgroup
-// (3 MFMA + 44 VALU instructions each) = 1.5 us of the fp64 pipe.
+// Per half step the dependency chain is: partials visible (hop) -> accept tests -> proposals -> kernel sums -> partial
+// stores.  Work per half step at C4: 512 x 5000 kernel evaluations = 40 tile products per workgroup (3 MFMA + 44 VALU
+// instructions each) = 1.5 us of the fp64 pipe.
 #include <cstdlib>
 #include <vector>
 #include "gp_device.hpp"
@@ -39,12 +44,15 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 #define ALABI_GRP_EMPTY 0x7FF8A1AB1D15EA5Eull   // the sentinel of the version history (ensemble.hip: ALABI_HIST_EMPTY)
 #define ALABI_GRP_MAXW 8                         // waves per workgroup (512 threads)
+#define ALABI_GRP_NPJ 2                          // partial words a lane may have to gather per pass (2 PPW G / 64)
 
 struct GroupArgs {
-    unsigned long long* hist;            // [(K+1)][E*W][d+2] version history, rows 1..K pre-filled with the sentinel
-    unsigned long long* part;            // [2K][E][NG][G][QPAD] partial kernel sums, pre-filled with the sentinel
+    unsigned long long* hist;            // [(K+1)][E*W][d+2] version history: row 0 = state before the launch, rows 1..K written here
+    unsigned long long* part;            // [2K][E][NG][QPAD][G] partial kernel sums, pre-filled with the sentinel
+    unsigned long long* cand;            // [2K][E][n0][2d+4] candidates, pre-filled with the sentinel
     int* err;                            // [1] time-out flag
     const unsigned long long* packed;    // proposal records of the chunk: [K][E][W][4] (walker | partner << 32, z, (d-1) ln z, ln u')
+    const unsigned long long* link;      // [K][E][W] producers of the two rows a proposal reads (ens_link_kernel)
     const double* consts;                // [5][ALABI_MAX_DIM]: 1/length scale, lower, upper, prior mean, prior 1/std
     const double* Xa;                    // [4 KS][Npad] augmented centred training rows
     const double* centre;                // [d] centre of the scaled training inputs
@@ -63,6 +71,14 @@ __device__ inline unsigned long long grp_ld(const unsigned long long* p) {
 __device__ inline void grp_st(unsigned long long* p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ inline unsigned long long grp_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+__device__ inline double grp_dbl(unsigned long long v) { return __longlong_as_double((long long)v); }
+
+// Workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for the
+// write-through candidate / partial stores and the record prefetch, none of which anybody reads through LDS.
+__device__ inline void grp_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // Sum over the lanes of a 16-lane DPP row, result in EVERY lane of the row, identical bits in all of them
 // (row_ror 8, 4, 2, 1: each step adds the same two operands in both lanes of a pair, and a + b == b + a).
@@ -74,31 +90,59 @@ __device__ inline double row16_allsum(double v) {
     return v;
 }
 
-// LDS layout (units of 8 bytes), the same formula on the host (ens_group_lds_words).
+// Where a row was produced: the proposal at position `ph` of the active list of chunk-local half step `hp`
+// (source = hp << 16 | ph), or -1 for version 0 (the state before the launch, hist row 0).  One thread per list position.
+__global__ void __launch_bounds__(256)
+ens_link_kernel(DrawBuffers b, int W, int n0) {
+    const int t = blockIdx.x, e = blockIdx.y, E = gridDim.y;
+    const size_t base = ((size_t)t * E + e) * W;
+    const int g0 = e * W;
+    for (int pos = threadIdx.x; pos < W; pos += 256) {
+        const int wl = b.order[base + pos] - g0, cl = b.cw[base + pos] - g0;
+        const int split = pos >= n0;
+        auto src = [&](int version, int xl) -> int {
+            if (version == 0) return -1;
+            const int pp = b.pos_of[((size_t)(version - 1) * E + e) * W + xl];
+            const int set = pp >= n0;
+            return ((2 * (version - 1) + set) << 16) | (pp - set * n0);
+        };
+        b.link[base + pos] = (unsigned long long)(unsigned)src(t, wl) | ((unsigned long long)(unsigned)src(t + split, cl) << 32);
+    }
+}
+
+// LDS layout (units of 8 bytes), the same formula on the host.
 struct GroupLds {
-    int etab, xb, al, aop, wsum, rec, lpo, prior, inb, mq, mo, pj, dec, ctl, total;
+    int etab, xb, al, aop, wsum, rec, pw, rd, ctl, total;
 };
 __host__ __device__ inline GroupLds group_lds(int KS, int QPAD, int S, int G, int d) {
+    const int rows = (d + 2 <= 16) ? 8 : 4;   // rows (own + partner) a wave rebuilds per pass
     GroupLds L;
-    const int nmine = (QPAD + G - 1) / G;
     int o = 0;
     L.etab = o; o += 64;
     L.xb = o; o += S * KS * 4;            // S/16 tiles x KS k-steps x 64 lanes
     L.al = o; o += S;
     L.aop = o; o += QPAD * KS * 4;
     L.wsum = o; o += ALABI_GRP_MAXW * QPAD;
-    L.rec = o; o += 4 * QPAD * 4;         // ring of 4 half steps
-    L.lpo = o; o += 2 * QPAD;
-    L.prior = o; o += 2 * QPAD;
-    L.inb = o; o += 2 * QPAD;             // in-box flags (as 8-byte words)
-    L.mq = o; o += 2 * nmine * d;         // proposals / old coordinates of the walkers THIS member decides, by half-step parity
-    L.mo = o; o += 2 * nmine * d;
-    L.pj = o; o += nmine * G;
-    L.dec = o; o += 2 * nmine;            // decisions: new logp, accept flag
+    L.rec = o; o += 4 * QPAD * 5;         // ring of 4 half steps: 4 record words + 1 link word per proposal
+    L.pw = o; o += ALABI_GRP_MAXW * rows * G;   // per wave: the G partials of its rows
+    L.rd = o; o += ALABI_GRP_MAXW * 16;   // per wave: (logp, accepted) of up to 8 rows
     L.ctl = o; o += 2;
     L.total = o;
     return L;
 }
+
+#ifdef ALABI_GROUP_PROF
+// phase stamps (s_memrealtime, 100 MHz) of one workgroup, accumulated over the half steps of the last launch:
+// [0] rows phase (poll + accept tests) [1] proposals + barrier A [2] kernel sums [3] barrier B + partial stores [4] half steps
+// for the wave that forms the first proposals (NW - 1); [8..12] the same for wave 0 (which also publishes the partials)
+__device__ long long g_group_prof[16];
+extern "C" int alabi_debug_group_prof(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_group_prof), sizeof(long long) * 16);
+}
+#define GRP_STAMP(x) const long long x = (long long)__builtin_amdgcn_s_memrealtime()
+#else
+#define GRP_STAMP(x)
+#endif
 
 template <int KS, int Q, bool GENERIC>
 __global__ void __launch_bounds__(512)
@@ -113,18 +157,13 @@ ens_group_kernel(GroupArgs p) {
     double* aop = lds + L.aop;
     double* wsum = lds + L.wsum;
     unsigned long long* rec_s = reinterpret_cast<unsigned long long*>(lds + L.rec);
-    double* lpo_s = lds + L.lpo;
-    double* prior_s = lds + L.prior;
-    unsigned long long* inb_s = reinterpret_cast<unsigned long long*>(lds + L.inb);
-    double* mq_s = lds + L.mq;
-    double* mo_s = lds + L.mo;
-    double* pj_s = lds + L.pj;
-    double* dec_s = lds + L.dec;
     int* ctl_s = reinterpret_cast<int*>(lds + L.ctl);
 
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6, NW = T >> 6;
     const int e = blockIdx.y, E = gridDim.y;
-    const int G = p.G, NG = p.NG, d = p.d, row = d + 2, WT = p.W * E;
+    const int G = p.G, NG = p.NG, d = p.d, row = d + 2, WT = p.W * E, CW = 2 * d + 4;
+    double* pw_w = lds + L.pw + wv * ((d + 2 <= 16) ? 8 : 4) * G;   // wave-private
+    double* rd_w = lds + L.rd + wv * 16;
     int g, m;
     {
         const int b = blockIdx.x, B = NG * G;
@@ -152,71 +191,250 @@ ens_group_kernel(GroupArgs p) {
     if (tid < 2) ctl_s[tid] = 0;
     const int LPR = (d + 2 <= 16) ? 16 : 32;                 // lanes per proposal in the row / proposal phase
     const int lshift = (LPR == 16) ? 4 : 5;
-    const int k = tid & (LPR - 1);                           // this thread's word of a row: k < d coordinate, k == d logp
-    const int PPP = T >> lshift;                             // proposals per pass over the workgroup
+    const int k = lane & (LPR - 1);                          // this lane's word of a row: k < d coordinate, k == d logp
+    const int pl = lane >> lshift;                           // proposal slot within the wave
+    const int PPW = 64 >> lshift, PPP = NW * PPW;            // proposals per wave / per pass over the workgroup
     const int npass = (QPAD + PPP - 1) / PPP;
+    const int pwv = NW - 1 - wv;                             // the LAST wave takes the first proposals: wave 0 publishes the partials
     const double il_r = (k < d) ? p.consts[k] : 0.0, lo_r = (k < d) ? p.consts[ALABI_MAX_DIM + k] : 0.0;
     const double hi_r = (k < d) ? p.consts[2 * ALABI_MAX_DIM + k] : 0.0;
     const double pm_r = (k < d) ? p.consts[3 * ALABI_MAX_DIM + k] : 0.0, pi_r = (k < d) ? p.consts[4 * ALABI_MAX_DIM + k] : 0.0;
     const double c_r = (k < d) ? p.centre[k] : 0.0;
     const double SC = GENERIC ? 1.0 : ALABI_EXP2S_SCALE;
+    // partial words this lane gathers per pass: word u is partial j_u of row r_u (rows 2 s, 2 s + 1: own / partner row of slot s)
+    const int npj = (2 * PPW * G + 63) >> 6;
+    int pj_r[ALABI_GRP_NPJ], pj_j[ALABI_GRP_NPJ];
+#pragma unroll
+    for (int u = 0; u < ALABI_GRP_NPJ; ++u) {
+        const int idx = lane + 64 * u;
+        pj_r[u] = idx / G;
+        pj_j[u] = idx - pj_r[u] * G;
+        if (u >= npj || pj_r[u] >= 2 * PPW) pj_r[u] = -1;
+    }
 
     // ---- proposal records: ring of 4 half steps in LDS, fetched three half steps ahead (plain loads: written before the launch)
     const int n1 = p.W - p.n0;
     auto half_count = [&](int hh) { const int nh = (hh & 1) ? n1 : p.n0; int c = nh - g * p.QP; c = c < 0 ? 0 : c; return c > p.QP ? p.QP : c; };
+    constexpr int RW = 5 * QPAD;                             // ring words per half step
     auto rec_load = [&](int hh, int i) -> unsigned long long {       // word i of the group's record block of half step hh
-        if (hh >= 2 * p.K || i >= 4 * half_count(hh)) return 0xFFFFFFFFFFFFFFFFull;
+        if (hh >= 2 * p.K) return 0xFFFFFFFFFFFFFFFFull;
+        const int c = half_count(hh);
         const size_t pos0 = ((size_t)(hh >> 1) * E + e) * p.W + ((hh & 1) ? p.n0 : 0) + (size_t)g * p.QP;
-        return p.packed[4 * pos0 + i];
+        if (i < 4 * QPAD) return (i < 4 * c) ? p.packed[4 * pos0 + i] : 0xFFFFFFFFFFFFFFFFull;
+        return (i - 4 * QPAD < c) ? p.link[pos0 + (i - 4 * QPAD)] : 0xFFFFFFFFFFFFFFFFull;
     };
-    constexpr int RW = 4 * QPAD;                             // record words per half step
-    unsigned long long pend[(RW + 255) / 256];               // T >= 256
-    for (int hh = 0; hh < 2; ++hh)
-        for (int i = tid; i < RW; i += T) rec_s[(hh & 3) * RW + i] = rec_load(hh, i);
+    // wave 0 owns the ring: its other memory traffic is the partial stores, so the counted wait in front of the LDS write
+    // never sits behind a candidate store or a poll of the row phase
+    constexpr int NRL = (RW + 63) / 64;
+    unsigned long long pend[NRL];
+    if (wv == 0) {
+        for (int hh = 0; hh < 2; ++hh)
+            for (int i = lane; i < RW; i += 64) rec_s[(hh & 3) * RW + i] = rec_load(hh, i);
 #pragma unroll
-    for (int j = 0; j < (RW + 255) / 256; ++j) pend[j] = (tid + j * T < RW) ? rec_load(2, tid + j * T) : 0ull;
+        for (int j = 0; j < NRL; ++j) pend[j] = (lane + j * 64 < RW) ? rec_load(2, lane + j * 64) : 0ull;
+    }
+    for (int i = tid; i < ALABI_GRP_MAXW * QPAD; i += T) wsum[i] = 0.0;   // waves beyond NW contribute nothing
     __syncthreads();
 
     const int tpw = (ntile + NW - 1) / NW;                   // point tiles per wave
     const int tl_begin = wv * tpw, tl_end = (tl_begin + tpw < ntile) ? tl_begin + tpw : ntile;
     const int lr = lane & 15, lk = lane >> 4;
-    const int nmine_max = (QPAD + G - 1) / G;
 
-    for (int hh = 0; hh < 2 * p.K; ++hh) {
-        const int t = hh >> 1, split = hh & 1, par = hh & 1;
-        const int cnt = half_count(hh);
-        const unsigned long long* rs = rec_s + (hh & 3) * RW;
-        // ---- phase 1: poll the rows, form the proposals, publish the A operands in LDS ----
-        int ok = 1;
-        for (int ps = 0; ps < npass; ++ps) {
-            const int pp = ps * PPP + (tid >> lshift);
-            const bool valid = pp < cnt;
-            double sv = 0.0, qv = 0.0, zz = 0.0;
+    // Rows of this wave's proposals in ALL passes of a half step, rebuilt from candidates + partials (wave-level: every lane
+    // of the wave takes part).  Pass ps, slot pl is proposal ps PPP + pwv PPW + pl of the record block `rs`.  Lane (slot,
+    // word k) gets word k of the own row in sv_[ps] (k < d coordinate, k == d logp), coordinate k of the partner row in
+    // cv_[ps], and acc_[ps] = was the own row's producing proposal accepted.  A source < 0 is hist row 0.  All first looks of
+    // all passes are issued before any is examined: one memory round trip when everything is there.
+    // tail_hf >= 0: the rows the proposals of half step tail_hf PRODUCED are wanted (own rows only, source (tail_hf, position)).
+    constexpr int NPM = (Q == 1) ? 1 : (Q == 2) ? 2 : 4;     // passes (the host only picks blockings with npass <= NPM)
+    int w_[NPM], cw_[NPM], so_[NPM], sp_[NPM];
+    double sv_[NPM], cv_[NPM];
+    int acc_[NPM];
+#ifdef ALABI_GROUP_PROF
+    long long prof_poll = 0, prof_setup = 0;
+#endif
+    auto rows_phase = [&](const unsigned long long* rs, int cnt, int tail_hf) -> int {
+        const bool want_partner = tail_hf < 0;
+        if (pwv * PPW >= cnt) {                              // wave-uniform: none of this wave's slots holds a proposal
+#pragma unroll
+            for (int ps = 0; ps < NPM; ++ps) { w_[ps] = 0; cw_[ps] = 0; so_[ps] = -1; sp_[ps] = -1; sv_[ps] = 0.0; cv_[ps] = 0.0; acc_[ps] = 0; }
+            return 1;
+        }
+        unsigned long long v_[NPM][4];
+        double pv_[NPM][ALABI_GRP_NPJ];
+        const unsigned long long* a_[NPM][4];
+        const unsigned long long* pa_[NPM][ALABI_GRP_NPJ];
+        unsigned want_[NPM], got_[NPM];
+#pragma unroll
+        for (int ps = 0; ps < NPM; ++ps) {
+            const int ppbase = ps * PPP + pwv * PPW, pp = ppbase + pl;
+            const bool valid = ps < npass && pp < cnt;
+            unsigned want = 0u;
+            w_[ps] = 0; cw_[ps] = 0; so_[ps] = -1; sp_[ps] = -1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a_[ps][i] = nullptr; v_[ps][i] = 0ull; }
             if (valid) {
                 const unsigned long long ids = rs[4 * pp];
-                const int w = (int)(unsigned)(ids & 0xffffffffull), cw = (int)(unsigned)(ids >> 32);
-                zz = __longlong_as_double((long long)rs[4 * pp + 1]);
-                const unsigned long long* hw = p.hist + ((size_t)t * WT + w) * row + k;
-                const unsigned long long* hc = p.hist + ((size_t)(t + split) * WT + cw) * row + k;
-                const bool mine = k <= d, needc = k < d;
-                unsigned long long ws = mine ? ALABI_GRP_EMPTY : 0ull, wc = needc ? ALABI_GRP_EMPTY : 0ull;
-                int spins = 0;
-                while (true) {
-                    if (ws == ALABI_GRP_EMPTY) ws = grp_ld(hw);
-                    if (wc == ALABI_GRP_EMPTY) wc = grp_ld(hc);
-                    if (ws != ALABI_GRP_EMPTY && wc != ALABI_GRP_EMPTY) break;
-                    if (++spins > p.spin_limit ||
-                        ((spins & 63) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        ok = 0;
-                        break;
-                    }
+                w_[ps] = (int)(unsigned)(ids & 0xffffffffull); cw_[ps] = (int)(unsigned)(ids >> 32);
+                if (tail_hf >= 0) {
+                    so_[ps] = (tail_hf << 16) | (g * p.QP + pp);
+                } else {
+                    const unsigned long long lw = rs[4 * QPAD + pp];
+                    so_[ps] = (int)(unsigned)(lw & 0xffffffffull); sp_[ps] = (int)(unsigned)(lw >> 32);
                 }
-                sv = __longlong_as_double((long long)ws);
-                if (needc) {
-                    const double cv = __longlong_as_double((long long)wc);
-                    qv = cv - (cv - sv) * zz;
+                const int src_o = so_[ps], src_p = sp_[ps];
+                const unsigned long long* co = (src_o >= 0) ? p.cand + (((size_t)(src_o >> 16) * E + e) * p.n0 + (src_o & 0xffff)) * CW : nullptr;
+                const unsigned long long* cp = (want_partner && src_p >= 0)
+                                                   ? p.cand + (((size_t)(src_p >> 16) * E + e) * p.n0 + (src_p & 0xffff)) * CW : nullptr;
+                if (k < d) {
+                    if (co) { a_[ps][0] = co + k; a_[ps][1] = co + d + k; want |= 3u; }
+                    else { a_[ps][1] = p.hist + (size_t)w_[ps] * row + k; want |= 2u; }
+                    if (want_partner) {
+                        if (cp) { a_[ps][2] = cp + k; a_[ps][3] = cp + d + k; want |= 12u; }
+                        else { a_[ps][3] = p.hist + (size_t)cw_[ps] * row + k; want |= 8u; }
+                    }
+                } else if (k == d) {
+                    if (co) { a_[ps][0] = co + 2 * d; a_[ps][1] = a_[ps][0] + 1; a_[ps][2] = a_[ps][0] + 2; a_[ps][3] = a_[ps][0] + 3; want |= 15u; }
+                    else { a_[ps][0] = p.hist + (size_t)w_[ps] * row + d; want |= 1u; }
+                } else if (k == d + 1 && cp) {
+                    a_[ps][0] = cp + 2 * d; a_[ps][1] = a_[ps][0] + 1; a_[ps][2] = a_[ps][0] + 2; a_[ps][3] = a_[ps][0] + 3; want |= 15u;
                 }
             }
+            // partial words: row r_u belongs to slot r_u >> 1 of this wave (own row: even, partner row: odd)
+#pragma unroll
+            for (int u = 0; u < ALABI_GRP_NPJ; ++u) {
+                pa_[ps][u] = nullptr; pv_[ps][u] = 0.0;
+                if (ps < npass && pj_r[u] >= 0) {
+                    const int sl = pj_r[u] >> 1, which = pj_r[u] & 1;
+                    if (ppbase + sl < cnt && (which == 0 || want_partner)) {
+                        int src;
+                        if (tail_hf >= 0) {
+                            src = (tail_hf << 16) | (g * p.QP + ppbase + sl);
+                        } else {
+                            const unsigned long long lw = rs[4 * QPAD + ppbase + sl];
+                            src = which ? (int)(unsigned)(lw >> 32) : (int)(unsigned)(lw & 0xffffffffull);
+                        }
+                        if (src >= 0) {
+                            const int ph = src & 0xffff, gq = ph / QPAD, pq = ph - gq * QPAD;
+                            pa_[ps][u] = p.part + ((((size_t)(src >> 16) * E + e) * NG + gq) * QPAD + pq) * G + pj_j[u];
+                            want |= 16u << u;
+                        }
+                    }
+                }
+            }
+            want_[ps] = want; got_[ps] = 0u;
+        }
+        int spins = 0, ok = 1;
+#ifdef ALABI_GROUP_PROF
+        prof_setup = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+        while (true) {
+            unsigned long long tv[NPM][4], tp[NPM][ALABI_GRP_NPJ];
+            unsigned miss[NPM];
+#pragma unroll
+            for (int ps = 0; ps < NPM; ++ps) {               // every look of this round is issued ...
+                miss[ps] = want_[ps] & ~got_[ps];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { tv[ps][i] = 0ull; if (miss[ps] & (1u << i)) tv[ps][i] = grp_ld(a_[ps][i]); }
+#pragma unroll
+                for (int u = 0; u < ALABI_GRP_NPJ; ++u) { tp[ps][u] = 0ull; if (miss[ps] & (16u << u)) tp[ps][u] = grp_ld(pa_[ps][u]); }
+            }
+            bool all = true;
+#pragma unroll
+            for (int ps = 0; ps < NPM; ++ps) {               // ... before any is examined
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if ((miss[ps] & (1u << i)) && tv[ps][i] != ALABI_GRP_EMPTY) { v_[ps][i] = tv[ps][i]; got_[ps] |= 1u << i; }
+#pragma unroll
+                for (int u = 0; u < ALABI_GRP_NPJ; ++u)
+                    if ((miss[ps] & (16u << u)) && tp[ps][u] != ALABI_GRP_EMPTY) { pv_[ps][u] = grp_dbl(tp[ps][u]); got_[ps] |= 16u << u; }
+                all = all && got_[ps] == want_[ps];
+            }
+            if (all) break;
+            if (++spins > p.spin_limit ||
+                ((spins & 63) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                ok = 0;
+                break;
+            }
+        }
+#ifdef ALABI_GROUP_PROF
+        prof_poll = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+        for (int ps = 0; ps < NPM; ++ps) {
+            const int ppbase = ps * PPP + pwv * PPW, pp = ppbase + pl;
+            sv_[ps] = 0.0; cv_[ps] = 0.0; acc_[ps] = 0;
+            if (ps >= npass || ppbase >= cnt) continue;      // wave-uniform
+            const bool valid = pp < cnt;
+#pragma unroll
+            for (int u = 0; u < ALABI_GRP_NPJ; ++u)
+                if (pa_[ps][u]) pw_w[pj_r[u] * G + pj_j[u]] = pv_[ps][u];
+            __builtin_amdgcn_wave_barrier();
+            // accept tests of the producing proposals: lane k == d for the own row, lane k == d + 1 for the partner row
+            if (valid && (k == d || (k == d + 1 && want_partner))) {
+                const int r = 2 * pl + (k - d);
+                const int src = (k == d) ? so_[ps] : sp_[ps];
+                double lp = grp_dbl(v_[ps][0]), flag = 0.0;  // source < 0: version 0, logp from hist row 0 (own row only)
+                if (src >= 0 && ok) {
+                    double sm = 0.0;
+                    for (int j = 0; j < G; ++j) sm += pw_w[r * G + j];
+                    const double lp_old = grp_dbl(v_[ps][0]), lnfac = grp_dbl(v_[ps][1]), lnu = grp_dbl(v_[ps][2]), prior = grp_dbl(v_[ps][3]);
+                    const double lp_new = fma(p.amp, sm, p.mean) + prior;
+                    const int acc_flag = (lnfac + lp_new - lp_old > lnu) ? 1 : 0;
+                    lp = acc_flag ? lp_new : lp_old;
+                    flag = acc_flag ? 1.0 : 0.0;
+                }
+                rd_w[2 * r] = lp;
+                rd_w[2 * r + 1] = flag;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double lp_o = rd_w[4 * pl], fl_o = rd_w[4 * pl + 1], fl_p = want_partner ? rd_w[4 * pl + 3] : 0.0;
+            __builtin_amdgcn_wave_barrier();                 // the next pass overwrites rd_w / pw_w
+            acc_[ps] = (so_[ps] >= 0 && fl_o != 0.0) ? 1 : 0;
+            if (valid) {
+                if (k < d) {
+                    sv_[ps] = grp_dbl(acc_[ps] ? v_[ps][0] : v_[ps][1]);
+                    cv_[ps] = grp_dbl((sp_[ps] >= 0 && fl_p != 0.0) ? v_[ps][2] : v_[ps][3]);
+                } else if (k == d) {
+                    sv_[ps] = lp_o;
+                }
+            }
+        }
+        return ok;
+    };
+
+#ifdef ALABI_GROUP_PROF
+    long long prof[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
+    // per-pass constants of this lane: is this member responsible for the slot's proposal, where its candidate goes
+    bool mine_[NPM];
+    int cand_off_[NPM];
+#pragma unroll
+    for (int ps = 0; ps < NPM; ++ps) {
+        const int pp = ps * PPP + pwv * PPW + pl;
+        mine_[ps] = (pp % G) == m;
+        cand_off_[ps] = (g * p.QP + pp) * CW;
+    }
+    unsigned long long* cand_h = p.cand + (size_t)e * p.n0 * CW;       // candidates of the current half step
+    const size_t cand_stride = (size_t)E * p.n0 * CW;
+    for (int hh = 0; hh < 2 * p.K; ++hh, cand_h += cand_stride) {
+        const int t = hh >> 1;
+        const int cnt = half_count(hh);
+        const unsigned long long* rs = rec_s + (hh & 3) * RW;
+        // ---- phase 1: rebuild the rows, form the proposals, publish candidates and the A operands ----
+        GRP_STAMP(c0);
+        const int ok = rows_phase(rs, cnt, -1);
+        GRP_STAMP(c1);
+#pragma unroll
+        for (int ps = 0; ps < NPM; ++ps) {
+            const int ppbase = ps * PPP + pwv * PPW;
+            if (ps >= npass || ppbase >= QPAD) continue;     // wave-uniform
+            const int pp = ppbase + pl;
+            const bool valid = pp < cnt;
+            const int w = w_[ps], acc_o = acc_[ps];
+            const double sv = sv_[ps], cv = cv_[ps];
+            const double zz = valid ? grp_dbl(rs[4 * pp + 1]) : 0.0;
+            const double qv = (valid && k < d) ? cv - (cv - sv) * zz : 0.0;
             // lanes of one proposal: k = 0 .. LPR-1.  In-box test, |q - c|^2 and the normal-prior term by segmented reductions.
             const int out = (valid && k < d) ? !((qv > lo_r) && (qv < hi_r)) : 0;
             const unsigned long long om = __ballot(out);
@@ -237,28 +455,32 @@ ens_group_kernel(GroupArgs p) {
                 if (valid) av = (k < d) ? qs * SC : (k == d) ? SC : (k == d + 1) ? -0.5 * qq * SC : 0.0;
                 aop[pp * KP + k] = av;
             }
-            if (valid) {
-                if (k == 0) { inb_s[par * QPAD + pp] = (seg == 0ull) ? 1ull : 0ull; prior_s[par * QPAD + pp] = pr + p.prior_const; }
-                if (k == d) lpo_s[par * QPAD + pp] = sv;
-                if (k < d && (pp % G) == m) {
-                    const int i = pp / G;
-                    mq_s[(par * nmine_max + i) * d + k] = qv;
-                    mo_s[(par * nmine_max + i) * d + k] = sv;
-                }
+            if (valid && mine_[ps]) {
+                // candidate of this proposal (everything the accept test needs but the kernel sum), for whoever reads the row later
+                unsigned long long* cn = cand_h + cand_off_[ps];
+                if (k < d) { grp_st(cn + k, grp_bits(qv)); grp_st(cn + d + k, grp_bits(sv)); }
+                else if (k == d) { grp_st(cn + 2 * d, grp_bits(sv)); grp_st(cn + 2 * d + 3, grp_bits(seg == 0ull ? pr + p.prior_const : -INFINITY)); }
+                else if (k == d + 1) { grp_st(cn + 2 * d + 1, rs[4 * pp + 2]); grp_st(cn + 2 * d + 2, rs[4 * pp + 3]); }
+                // the chain: version t of the own walker (t = 0 is already there)
+                if (t > 0 && k <= d + 1)
+                    p.hist[((size_t)t * WT + w) * row + k] = (k <= d) ? grp_bits(sv) : (unsigned long long)acc_o;
             }
         }
         if (!ok) {
             ctl_s[0] = 1;
             __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __syncthreads();                                     // barrier A: A operands (and the abort word) are in LDS
+        grp_barrier();                                       // barrier A: A operands (and the abort word) are in LDS
+        GRP_STAMP(c2);
         if (ctl_s[0]) return;
         // records: slot hh+2 from the registers, issue hh+3 (lands under this half step's kernel sums)
+        if (wv == 0) {
 #pragma unroll
-        for (int j = 0; j < (RW + 255) / 256; ++j)
-            if (tid + j * T < RW) rec_s[((hh + 2) & 3) * RW + tid + j * T] = pend[j];
+            for (int j = 0; j < NRL; ++j)
+                if (lane + j * 64 < RW) rec_s[((hh + 2) & 3) * RW + lane + j * 64] = pend[j];
 #pragma unroll
-        for (int j = 0; j < (RW + 255) / 256; ++j) pend[j] = (tid + j * T < RW) ? rec_load(hh + 3, tid + j * T) : 0ull;
+            for (int j = 0; j < NRL; ++j) pend[j] = (lane + j * 64 < RW) ? rec_load(hh + 3, lane + j * 64) : 0ull;
+        }
         // ---- phase 2: kernel sums of the QP proposals over this member's slice, on the matrix cores ----
         double a[Q][KS];
 #pragma unroll
@@ -268,7 +490,6 @@ ens_group_kernel(GroupArgs p) {
         v4f64 sum[Q];
 #pragma unroll
         for (int qt = 0; qt < Q; ++qt) sum[qt] = v4f64{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
         for (int tl = tl_begin; tl < tl_end; ++tl) {
             const double* xbt = xb + (size_t)tl * KS * 64 + lane;
             double bop[KS];
@@ -298,66 +519,38 @@ ens_group_kernel(GroupArgs p) {
                 v += dpp_move<0x118, 0xf>(v);
                 if (lr == 15) wsum[wv * QPAD + qt * 16 + lk + 4 * i] = v;
             }
-        __syncthreads();                                     // barrier B: the wave partials are in LDS
-        if (wv != 0) continue;                               // waves 1.. go straight to the next half step's rows
-        // ---- phase 3 (wave 0): this member's partial sums, published like rows ----
-        unsigned long long* part_h = p.part + (((size_t)hh * E + e) * NG + g) * (size_t)G * QPAD;
-        for (int pp = lane; pp < cnt; pp += 64) {
-            double s = 0.0;
-            for (int w = 0; w < NW; ++w) s += wsum[w * QPAD + pp];
-            grp_st(part_h + (size_t)m * QPAD + pp, (unsigned long long)__double_as_longlong(s));
-        }
-        // ---- phase 4 (wave 0): proposals m, m + G, ...: gather the G partials, accept test, new rows ----
-        const int nm = (cnt > m) ? (cnt - m + G - 1) / G : 0;
-        int ok4 = 1;
-        for (int base = 0; base < nm * G; base += 64) {
-            const int idx = base + lane;
-            if (idx < nm * G) {
-                const int i = idx / G, j = idx % G;
-                const unsigned long long* src = part_h + (size_t)j * QPAD + (m + i * G);
-                unsigned long long v = ALABI_GRP_EMPTY;
-                int spins = 0;
-                while (true) {
-                    v = grp_ld(src);
-                    if (v != ALABI_GRP_EMPTY) break;
-                    if (++spins > p.spin_limit ||
-                        ((spins & 63) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        ok4 = 0;
-                        break;
-                    }
-                }
-                pj_s[idx] = __longlong_as_double((long long)v);
+        GRP_STAMP(c3);
+        grp_barrier();                                       // barrier B: the wave partials are in LDS
+        // ---- phase 3 (wave 0): this member's partial sums, published like rows; the other waves go on ----
+        if (wv == 0) {
+            unsigned long long* part_h = p.part + (((size_t)hh * E + e) * NG + g) * (size_t)QPAD * G + m;
+            for (int pp = lane; pp < cnt; pp += 64) {
+                double x[ALABI_GRP_MAXW];
+#pragma unroll
+                for (int w = 0; w < ALABI_GRP_MAXW; ++w) x[w] = wsum[w * QPAD + pp];
+                const double s = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                grp_st(part_h + (size_t)pp * G, grp_bits(s));
             }
         }
-        if (!__all(ok4)) {                                   // the other waves see the abort word at their next barrier A
-            if (lane == 0) { ctl_s[0] = 1; __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            continue;
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < nm; i += 64) {
-            const int pp = m + i * G;
-            double s = 0.0;
-            for (int j = 0; j < G; ++j) s += pj_s[i * G + j];
-            double lp_new = -INFINITY;
-            if (inb_s[par * QPAD + pp]) lp_new = fma(p.amp, s, p.mean) + prior_s[par * QPAD + pp];
-            const double lp_old = lpo_s[par * QPAD + pp];
-            const double lnfac = __longlong_as_double((long long)rs[4 * pp + 2]);
-            const double lnu = __longlong_as_double((long long)rs[4 * pp + 3]);
-            const int acc_flag = (lnfac + lp_new - lp_old > lnu) ? 1 : 0;
-            dec_s[2 * i] = acc_flag ? lp_new : lp_old;
-            dec_s[2 * i + 1] = acc_flag ? 1.0 : 0.0;
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int idx = lane; idx < nm * row; idx += 64) {
-            const int i = idx / row, kk = idx % row, pp = m + i * G;
-            const int w = (int)(unsigned)(rs[4 * pp] & 0xffffffffull);
-            const bool accd = dec_s[2 * i + 1] != 0.0;
-            unsigned long long outw;
-            if (kk < d) outw = (unsigned long long)__double_as_longlong(accd ? mq_s[(par * nmine_max + i) * d + kk]
-                                                                              : mo_s[(par * nmine_max + i) * d + kk]);
-            else if (kk == d) outw = (unsigned long long)__double_as_longlong(dec_s[2 * i]);
-            else outw = accd ? 1ull : 0ull;
-            grp_st(p.hist + ((size_t)(t + 1) * WT + w) * row + kk, outw);
+#ifdef ALABI_GROUP_PROF
+        { GRP_STAMP(c4); prof[0] += c1 - c0; prof[1] += c2 - c1; prof[2] += c3 - c2; prof[3] += c4 - c3; prof[4] += 1;
+          prof[5] += prof_setup - c0; prof[6] += prof_poll - prof_setup; }
+#endif
+    }
+#ifdef ALABI_GROUP_PROF
+    if (blockIdx.x == 5 && blockIdx.y == 0 && lane == 0 && (wv == NW - 1 || wv == 0))
+        for (int i = 0; i < 7; ++i) g_group_prof[(wv == 0 ? 8 : 0) + i] = prof[i];
+#endif
+    // ---- tail: version K of every walker (nobody reads it inside the launch): the proposals of the last two half steps ----
+    for (int hf = 2 * p.K - 2; hf < 2 * p.K; ++hf) {
+        const int cnt = half_count(hf);
+        const int ok = rows_phase(rec_s + (hf & 3) * RW, cnt, hf);
+        if (!ok) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int ps = 0; ps < NPM; ++ps) {
+            const int pp = ps * PPP + pwv * PPW + pl;
+            if (ps < npass && pp < cnt && ok && mine_[ps] && k <= d + 1)
+                p.hist[((size_t)p.K * WT + w_[ps]) * row + k] = (k <= d) ? grp_bits(sv_[ps]) : (unsigned long long)acc_[ps];
         }
     }
 }
@@ -396,14 +589,20 @@ static GroupPlan group_plan(const alabi_ens* e) {
     int force_q = 0, force_g = 0;
     if (const char* env = getenv("ALABI_ENS_GROUP_Q")) force_q = atoi(env);
     if (const char* env = getenv("ALABI_ENS_GROUP_G")) force_g = atoi(env);
+    int threads = 512;
+    if (const char* env = getenv("ALABI_ENS_GROUP_THREADS")) { const int v = atoi(env); if (v == 256 || v == 512) threads = v; }
+    const int ppw = (d + 2 <= 16) ? 4 : 2;                   // proposals per wave and pass of the row phase (16 / 32 lanes each)
+    const int g_cap = 64 * ALABI_GRP_NPJ / (2 * ppw);        // partial words a lane gathers per pass: 2 ppw G / 64 <= NPJ
     double best_cost = 0.0;
     for (int Q = 1; Q <= 8; Q *= 2) {
         if (force_q && Q != force_q) continue;
         const int QP = 16 * Q;
+        const int npm = (Q == 1) ? 1 : (Q == 2) ? 2 : 4;     // passes the kernel instantiation provides
+        if ((QP + (threads / 64) * ppw - 1) / ((threads / 64) * ppw) > npm) continue;
         const int NG = (n0 + QP - 1) / QP;
         if (NG > avail) continue;
         int G = avail / NG;
-        if (G > 64) G = 64;
+        if (G > g_cap) G = g_cap;
         if (G > tiles) G = tiles;
         if (force_g && force_g <= G) G = force_g;
         if (G < 1) continue;
@@ -417,10 +616,7 @@ static GroupPlan group_plan(const alabi_ens* e) {
             best_cost = cost;
         }
     }
-    if (best.ok) {
-        best.threads = 512;
-        if (const char* env = getenv("ALABI_ENS_GROUP_THREADS")) { const int v = atoi(env); if (v == 256 || v == 512) best.threads = v; }
-    }
+    best.threads = threads;
     return best;
 }
 
@@ -478,10 +674,20 @@ int launch_ens_group(alabi_ens* e, double* coords, double* logp, int K, int thin
         ALABI_HIP_CHECK(hipMalloc(&e->part, part_words * sizeof(unsigned long long)));
         e->part_words = part_words;
     }
+    const int n0 = (e->W + 1) / 2;
+    const size_t cand_words = (size_t)2 * e->chunk_cap * e->E * n0 * (2 * e->d + 4);
+    if (e->cand_words < cand_words) {
+        if (e->cand) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(e->cand); e->cand = nullptr; e->cand_words = 0; }
+        ALABI_HIP_CHECK(hipMalloc(&e->cand, cand_words * sizeof(unsigned long long)));
+        e->cand_words = cand_words;
+    }
     hipLaunchKernelGGL(ens_group_fill_kernel, dim3(2048), dim3(256), 0, s, e->part, (size_t)2 * K * e->E * pl.NG * pl.G * pl.QP);
-    if ((st = launch_ens_hist_prologue(e, coords, logp, K, s)) != ALABI_OK) return st;
+    hipLaunchKernelGGL(ens_group_fill_kernel, dim3(2048), dim3(256), 0, s, e->cand, (size_t)2 * K * e->E * n0 * (2 * e->d + 4));
+    hipLaunchKernelGGL(ens_link_kernel, dim3(K, e->E), dim3(256), 0, s, e->draws, e->W, n0);
+    if ((st = launch_ens_hist_prologue(e, coords, logp, K, false, s)) != ALABI_OK) return st;
     GroupArgs a{};
-    a.hist = e->hist; a.part = e->part; a.err = e->err; a.packed = e->draws.packed; a.consts = e->consts;
+    a.hist = e->hist; a.part = e->part; a.cand = e->cand; a.err = e->err; a.packed = e->draws.packed; a.link = e->draws.link;
+    a.consts = e->consts;
     a.Xa = gp->Xa; a.centre = gp->xa_centre; a.alpha = gp->alpha;
     a.K = K; a.W = e->W; a.n0 = (e->W + 1) / 2; a.d = e->d; a.Npad = gp->Npad;
     a.NG = pl.NG; a.G = pl.G; a.QP = pl.QP; a.S = pl.S;

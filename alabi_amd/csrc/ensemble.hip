@@ -126,6 +126,7 @@ ens_draw_kernel(unsigned long long seed, const long long* __restrict__ run_state
         b.partner[base + pos] = pr;
         b.u_z[base + pos] = uz;
         b.u_acc[base + pos] = ua;
+        b.pos_of[base + i] = pos;
         write_record(b, base + pos, (int)g0 + i, (int)g0 + cw, uz, ua, a, d);
     }
 }
@@ -1182,11 +1183,11 @@ bool ens_stream_fits(const alabi_ens* e) { return ens_stream_ppt(e) > 0; }
             hipLaunchKernelGGL((ens_stream_kernel<D, PPT_, TMAX_, GENERIC>), dim3(e->stream_grid, e->E), dim3(T + 128), 0, s, a))) \
     }
 
-// Version history around a persistent launch of K steps: rows 1..K <- sentinel, row 0 <- (coords, logp) before it;
+// Version history around a persistent launch of K steps: rows 1..K <- sentinel (`fill`: when the rows are polled), row 0 <- (coords, logp) before it;
 // (coords, logp) <- row K, chain / counters <- rows 1..K after it.  Shared by ens_stream_kernel and ens_group_kernel.
-int launch_ens_hist_prologue(alabi_ens* e, double* coords, double* logp, int K, hipStream_t s) {
+int launch_ens_hist_prologue(alabi_ens* e, double* coords, double* logp, int K, bool fill, hipStream_t s) {
     const int WT = e->W * e->E, row = e->d + 2;
-    hipLaunchKernelGGL(ens_hist_fill_kernel, dim3(1024), dim3(256), 0, s, e->hist + (size_t)WT * row, (size_t)K * WT * row);
+    if (fill) hipLaunchKernelGGL(ens_hist_fill_kernel, dim3(1024), dim3(256), 0, s, e->hist + (size_t)WT * row, (size_t)K * WT * row);
     hipLaunchKernelGGL(ens_hist_copy_kernel, dim3((WT * row + 255) / 256), dim3(256), 0, s, coords, logp, e->hist, WT, e->d, 1);
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
@@ -1209,7 +1210,7 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
     alabi_gp* gp = e->gp;
     const int WT = e->W * e->E;
     const int n0 = (e->W + 1) / 2;
-    { const int st0 = launch_ens_hist_prologue(e, coords, logp, K, s); if (st0 != ALABI_OK) return st0; }
+    { const int st0 = launch_ens_hist_prologue(e, coords, logp, K, true, s); if (st0 != ALABI_OK) return st0; }
     StreamArgs a{};
     a.hist = e->hist; a.err = e->err; a.rec = e->draws; a.consts = e->consts;
     a.Xt = gp->Xt; a.alpha = gp->alpha; a.chain = chain; a.chain_logp = chain_logp;

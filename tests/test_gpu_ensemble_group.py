@@ -149,7 +149,7 @@ def test_group_kernel_timeout_falls_back(monkeypatch):
     """A hand-off that cannot arrive within the spin limit: every workgroup leaves, the sampler restores the state and
     repeats the run on the launch-per-half-step path."""
     from alabi_amd import EnsembleSampler
-    g, o, y = _pair(400, 3, 11, ell2=5.0)
+    g, o, y = _pair(4000, 3, 11, ell2=5.0)     # enough kernel-sum time that the partials are never there at the second look
     bounds = np.array([[-3.0, 3.0]] * 3)
     p0 = np.random.RandomState(1).uniform(-2, 2, (16, 3))
     monkeypatch.setenv("ALABI_ENS_STREAM", "0")
