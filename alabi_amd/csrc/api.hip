@@ -440,7 +440,7 @@ static void free_draws(DrawBuffers& b) {
 static DrawBuffers offset_draws(const DrawBuffers& b, size_t off) {
     DrawBuffers r = b;
     r.order += off; r.cw += off; r.zz += off; r.lnfac += off; r.lnu += off;
-    r.partner += off; r.u_z += off; r.u_acc += off; r.packed += 4 * off; r.pos_of += off; r.link += off;
+    r.partner += off; r.u_z += off; r.u_acc += off; r.packed += 4 * off; r.pos_of += off; r.link += 2 * off;
     return r;
 }
 
@@ -483,7 +483,7 @@ int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* 
     if (err == hipSuccess) err = hipMalloc(&b.u_acc, n * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&b.packed, 4 * n * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMalloc(&b.pos_of, n * sizeof(int));
-    if (err == hipSuccess) err = hipMalloc(&b.link, n * sizeof(unsigned long long));
+    if (err == hipSuccess) err = hipMalloc(&b.link, 2 * n * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMalloc(&e->run_state, 4 * sizeof(long long));
     if (err == hipSuccess) err = hipMalloc(&e->consts, 5 * ALABI_MAX_DIM * sizeof(double));
     // persistent dataflow path: one workgroup per list position, all co-resident (at most one per CU)

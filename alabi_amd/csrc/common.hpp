@@ -110,7 +110,7 @@ struct DrawBuffers {
     double* u_acc;
     unsigned long long* packed;   // 4 words per list position: walker | partner << 32, zz, lnfac, lnu (persistent kernel)
     int* pos_of;     // list position (0..W-1 within the ensemble) of every walker, keyed by global walker id (inverse of `order`)
-    unsigned long long* link;     // group kernel: per list position, where the two rows the proposal reads were produced (ens_link_kernel)
+    unsigned long long* link;     // group kernel: 2 words per list position, where the two rows the proposal reads were produced (ens_link_kernel)
 };
 }  // namespace alabi
 
