@@ -136,7 +136,7 @@ struct GroupLds {
 __host__ __device__ inline GroupLds group_lds(int KS, int QPAD, int S) {
     GroupLds L;
     int o = 0;
-    L.etab = o; o += 64;
+    L.etab = o; o += 256;
     L.xb = o; o += S * KS * 4;            // S/16 tiles x KS k-steps x 64 lanes
     L.al = o; o += S;
     L.aop = o; o += QPAD * KS * 4;
@@ -208,7 +208,7 @@ ens_group_kernel(GroupArgs p) {
         xb[i] = p.Xa[(size_t)(4 * s + (ln >> 4)) * p.Npad + (size_t)(tile0 + tl) * 16 + (ln & 15)];
     }
     for (int i = tid; i < ntile * 16; i += 512) al_s[i] = p.alpha[(size_t)tile0 * 16 + i];
-    if (tid < 64) etab[tid] = exp2((double)tid * 0.015625);
+    if (tid < 256) etab[tid] = exp2((double)tid * 0.00390625);
     if (tid < 2) ctl_s[tid] = 0;
     for (int i = tid; i < NW * QPAD; i += 512) wsum[i] = 0.0;
     const int k = lane & (LPR - 1);                          // this lane's word of a row: k < d coordinate, k == d logp
@@ -219,7 +219,7 @@ ens_group_kernel(GroupArgs p) {
     const double hi_r = (k < d) ? p.consts[2 * ALABI_MAX_DIM + k] : 0.0;
     const double pm_r = (k < d) ? p.consts[3 * ALABI_MAX_DIM + k] : 0.0, pi_r = (k < d) ? p.consts[4 * ALABI_MAX_DIM + k] : 0.0;
     const double c_r = (k < d) ? p.centre[k] : 0.0;
-    const double SC = GENERIC ? 1.0 : ALABI_EXP2S_SCALE;
+    const double SC = GENERIC ? 1.0 : ALABI_EXP2S256_SCALE;
 
     // ---- proposal records: ring of 4 half steps in LDS, fetched three half steps ahead (plain loads: written before the launch).
     // Wave 0 owns the ring: its other memory traffic is the partial stores, so the counted wait in front of the LDS write
@@ -508,7 +508,7 @@ ens_group_kernel(GroupArgs p) {
                 for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qt][s], bop[s], acc, 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {                // C/D layout: row (proposal) lk + 4 i, column (point) lr
-                    const double f = GENERIC ? radial<true>(fmax(-2.0 * acc[i], 0.0), p.kf) : exp2s_tab64(acc[i], etab);
+                    const double f = GENERIC ? radial<true>(fmax(-2.0 * acc[i], 0.0), p.kf) : exp2s_tab256(acc[i], etab);
                     sum[qt][i] = fma(al, f, sum[qt][i]);
                 }
             }

@@ -126,6 +126,26 @@ __device__ inline double exp2s_tab64(double s, const double* tab) {
     return ldexp(p * tj, ki >> 6);
 }
 
+// The same with a 256-entry table tab[j] = 2^(j/256) (2 KB of LDS) for an argument multiplied by 256 / ln2: |r| <= 1/2 is then
+// |x| <= ln2/512 and a degree-4 polynomial suffices (truncation x^5/120 = 3.8e-17): 10 instructions on the fp64 pipe (the clamp
+// costs two of them: the compiler quiets a possible signalling NaN before v_max_f64; an inline-asm v_max_f64 would save one but
+// reads the matrix-core result without the wait states only the compiler inserts).  <= 2.2 ulp against exp of the exact argument (2e5 samples, exact-arithmetic emulation).  Used by the group
+// ensemble kernel, whose time is the fp64 pipe's.
+#define ALABI_EXP2S256_SCALE 369.3299304675746                       /* 256 / ln2 */
+__device__ inline double exp2s_tab256(double s, const double* tab) {
+    s = fmax(s, -280064.0);
+    const double t = s + 0x1.8p52;
+    const double r = s - (t - 0x1.8p52);
+    const int ki = __double2loint(t);
+    const double tj = tab[ki & 255];
+    double p = 0x1.3b2ab6fba4e77p-39;                                /* (ln2/256)^4 / 4! */
+    p = fma(p, r, 0x1.c6b08d704a0c0p-29);                            /* (ln2/256)^3 / 3! */
+    p = fma(p, r, 0x1.ebfbdff82c58fp-19);                            /* (ln2/256)^2 / 2! */
+    p = fma(p, r, 0x1.62e42fefa39efp-9);                             /* ln2/256 */
+    p = fma(p, r, 1.0);
+    return ldexp(p * tj, ki >> 8);
+}
+
 // GENERIC = false compiles the squared-exponential alone (no run-time switch in the hot loops).
 template <bool GENERIC = true>
 __device__ inline double radial(double r2, KernelFn kf) {
