@@ -196,7 +196,6 @@ int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream) {
         ALABI_HIP_CHECK(hipStreamSynchronize(s));
         if (timed_out) {                                   // undefined matrix state: assemble and factorise again, step by step
             tasks_penalty.store(64, std::memory_order_relaxed);
-            if (getenv("ALABI_VERBOSE")) fprintf(stderr, "[alabi] task-queue Cholesky: a wait ran out (N=%d), falling back to the launch-per-step path\n", N);
             if ((st = launch_assemble(gp, s)) != ALABI_OK) return st;
             if ((st = launch_cholesky(gp, s)) != ALABI_OK) return st;
             ALABI_HIP_CHECK(hipMemcpyAsync(&info, gp->info, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -282,8 +281,7 @@ int alabi_gp_predict(alabi_gp* gp, const double* Xs, long long M, double* mu, do
         // utility.py:1030-1163, core.py:1441, and of small batches); measured cross-over against the tile kernels with the
         // split K* pre-pass: tools/prof_medium_batch.py
         const char* env = getenv("ALABI_PV_SMALL");
-        const char* envm = getenv("ALABI_PV_SMALL_MAX");
-        const long long small_max = envm ? atoll(envm) : (gp->Npad <= 2048 ? 128 : 64);
+        const long long small_max = gp->Npad <= 2048 ? 128 : 64;
         if (M <= small_max && gp->Npad >= 256 && gp->d <= 32 && !(env && env[0] == '0')) {
             (void)want_winv(gp, M);            // count the request
             return launch_predict_var_small(gp, Xs, (int)M, mu, var, s);
@@ -498,21 +496,9 @@ int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* 
             if (G > (W + 1) / 2) G = (W + 1) / 2;
             e->stream_grid = G;
             const size_t hist_words = ((size_t)e->chunk_cap + 1) * WT * (d + 2);   // row = coords, logp, accepted
-            if (err == hipSuccess) {
-                // the version history is the hand-off medium of the persistent kernels: fine-grained device memory shortens a
-                // cross-CU hop by ~15 % in the ping-pong micro-benchmark (tools/micro/pingpong); ALABI_ENS_HIST_FINE=0: plain
-                const char* fg = getenv("ALABI_ENS_HIST_FINE");
-                if (fg && fg[0] == '1') {
-                    err = hipExtMallocWithFlags(reinterpret_cast<void**>(&e->hist), hist_words * sizeof(unsigned long long),
-                                                hipDeviceMallocFinegrained);
-                    if (err != hipSuccess) { (void)hipGetLastError(); err = hipMalloc(&e->hist, hist_words * sizeof(unsigned long long)); }
-                } else {
-                    err = hipMalloc(&e->hist, hist_words * sizeof(unsigned long long));
-                }
-            }
+            if (err == hipSuccess) err = hipMalloc(&e->hist, hist_words * sizeof(unsigned long long));
             if (err == hipSuccess) err = hipMalloc(&e->err, sizeof(int));
             e->stream_ok = (err == hipSuccess) ? 1 : 0;
-            e->spec_ok = (e->stream_ok && (long long)W * n_ensembles <= n_cu) ? 1 : 0;
         }
     }
     if (err != hipSuccess) {
@@ -530,7 +516,6 @@ int alabi_ens_destroy(alabi_ens* e) {
     if (e->run_state) (void)hipFree(e->run_state);
     if (e->consts) (void)hipFree(e->consts);
     if (e->hist) (void)hipFree(e->hist);
-    if (e->prop) (void)hipFree(e->prop);
     if (e->part) (void)hipFree(e->part);
     if (e->cand) (void)hipFree(e->cand);
     if (e->err) (void)hipFree(e->err);

@@ -143,12 +143,10 @@ struct alabi_ens {
     long long* run_state = nullptr;  // device [4]: [0] first global step of the chunk, [1] steps done before it
     // persistent dataflow path (ens_stream_kernel)
     unsigned long long* hist = nullptr;  // [(chunk_cap+1)][E*W][d+1] version history of every walker
-    unsigned long long* prop = nullptr;  // [(chunk_cap+1)][E*W][d] proposals published by ens_spec_kernel (allocated on first use)
     int* err = nullptr;                  // [1] spin time-out flag
     int stream_grid = 0;                 // workgroups per ensemble of the persistent kernel
-    int last_path = 0;                   // 1 persistent kernel, 2 its speculative variant, 0 one launch per half step
+    int last_path = 0;                   // 1 persistent kernel (ens_stream_kernel), 3 group kernel (ens_group_kernel), 0 one launch per half step
     int stream_ok = 0;                   // eligible: training set fits the lanes' registers, one workgroup per CU
-    int spec_ok = 0;                     // W * E workgroups fit one per CU: the speculative persistent kernel (ens_spec_kernel)
     // group kernel (ens_group_kernel: training set partitioned over the members of a group, proposals streamed through)
     unsigned long long* part = nullptr;  // [2 chunk_cap][E][NG][G][16 Q] partial kernel sums (allocated on first use)
     size_t part_words = 0;

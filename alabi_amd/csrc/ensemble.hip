@@ -533,9 +533,6 @@ struct StreamArgs {
     unsigned long long* n_accept;
     const long long* run_state;
     int K, W, n0, d, Npad, thin_by, spin_limit, has_prior;
-    int poll_sleep;              // s_sleep(1) units between two looks of ens_stream_kernel's poll (0: none)
-    long long* dbg;              // nullable: per-workgroup counters of ens_spec_kernel (ALABI_SPEC_DBG=1)
-    unsigned long long* prop;    // nullable: [(K+1)][E*W][d] published proposals of ens_spec_kernel (sentinel-filled like hist)
     double amp, mean, prior_const;
     KernelFn kf;
 };
@@ -682,29 +679,6 @@ ens_stream_kernel(StreamArgs p) {
             unsigned long long ws = ALABI_HIST_EMPTY, wc = ALABI_HIST_EMPTY;
             int ok = 1, spins = 0;
             const bool mine = lane <= p.d, needc = lane < p.d;
-#ifdef ALABI_STREAM_POLL2
-            // two looks in flight: the second is issued before the first is examined (relaxed agent-scope loads are pipelined
-            // by the compiler with vmcnt(1)), so a row is seen at most half a round trip after it can be seen at all.
-            // Measured (round 2): correct, and 4 % SLOWER (6.18e7 vs 6.43e7 samples/s) -- as the 4-deep poll of round 1; off.
-            {
-                unsigned long long a_s = mine ? ld_sc1(hw) : 0ull, a_c = needc ? ld_sc1(hc) : 0ull, b_s, b_c;
-                while (true) {
-                    b_s = mine ? ld_sc1(hw) : 0ull; b_c = needc ? ld_sc1(hc) : 0ull;
-                    if (mine && ws == ALABI_HIST_EMPTY) ws = a_s;
-                    if (needc && wc == ALABI_HIST_EMPTY) wc = a_c;
-                    if (__all((!mine || ws != ALABI_HIST_EMPTY) && (!needc || wc != ALABI_HIST_EMPTY))) break;
-                    a_s = mine ? ld_sc1(hw) : 0ull; a_c = needc ? ld_sc1(hc) : 0ull;
-                    if (mine && ws == ALABI_HIST_EMPTY) ws = b_s;
-                    if (needc && wc == ALABI_HIST_EMPTY) wc = b_c;
-                    if (__all((!mine || ws != ALABI_HIST_EMPTY) && (!needc || wc != ALABI_HIST_EMPTY))) break;
-                    if ((spins += 2) > p.spin_limit ||
-                        ((spins & 62) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        ok = 0;
-                        break;
-                    }
-                }
-            }
-#else
             while (true) {
                 if (mine && ws == ALABI_HIST_EMPTY) ws = ld_sc1(hw);
                 if (needc && wc == ALABI_HIST_EMPTY) wc = ld_sc1(hc);
@@ -715,9 +689,7 @@ ens_stream_kernel(StreamArgs p) {
                     ok = 0;
                     break;
                 }
-                for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
             }
-#endif
 #ifdef ALABI_STREAM_PROF
             c1 = clock64();
 #endif
@@ -822,284 +794,6 @@ extern "C" int alabi_debug_stream_prof(long long* out) {
 }
 #endif
 
-// ---------------------------------------------------------------------------------------------------
-// Speculative variant of the persistent kernel, for W * E <= #CUs (the headline: ONE 256-walker ensemble on 256 CUs).
-// ens_stream_kernel leaves half the chip idle there (128 proposals per half step) and every half step costs
-//   hand-off (0.55 us) + proposal (0.15) + kernel sum (0.9) + accept / store (0.2)
-// in sequence.  Here every list position of BOTH halves has its own workgroup, so a workgroup owns one proposal per
-// STEP and is idle during the other half step.  It uses that time to evaluate its next proposal EARLY from stand-in
-// inputs: a row that has not been published yet is replaced by the walker's previous version, which is what the row
-// will turn out to be whenever that walker's pending update is rejected (59 % at the headline configuration; the
-// acceptance flag travels in the row).  When the real rows arrive and none of them changed, the kernel sum is already
-// there and only the accept test and the row store remain on the dependency chain; otherwise the proposal is formed
-// again from the real rows and evaluated as in ens_stream_kernel.  The result never depends on the guess: the value
-// that enters the accept test is always the sum evaluated at the proposal built from the real rows (same lane -> point
-// map and summation order as ens_half_kernel: chains stay bit-identical to the other two paths).
-// Rounds: an item (one proposal) consists of one or more rounds {barrier A: proposal in LDS; kernel sum; barrier B};
-// ctl_s[par][0] written by wave 0 before barrier B tells the other waves whether another round of the same item follows.
-template <int D, int PPT, int TMAX, bool GENERIC>
-__global__ void __launch_bounds__(TMAX)
-ens_spec_kernel(StreamArgs p) {
-    __shared__ __attribute__((aligned(16))) double scratch[2][16];
-    __shared__ unsigned long long rec_s[4][4];
-    __shared__ __attribute__((aligned(16))) double qs_s[2][ALABI_MAX_DIM];
-    __shared__ double consts_s[5][ALABI_MAX_DIM];
-    __shared__ int ctl_s[2][2];                                      // [round parity][0] 1 = item finished, no kernel sum; [0][1] abort
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int TC = blockDim.x - 128, nwc = TC >> 6;
-    const bool comm = wv == 0, service = wv == nwc + 1, compute = !comm && !service;
-    const int g = blockIdx.x, e = blockIdx.y, E = gridDim.y;
-    const int WT = p.W * E, row = p.d + 2;
-    const int split = g >= p.n0 ? 1 : 0;                  // this workgroup's list position g (set 0 then set 1), every step
-    const int half = p.Npad >> 1, ct = tid - 64;
-    f64x2 xa[PPT][D], aa[PPT];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int idx = ct + j * TC;
-        const bool v = compute && idx < half;
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-            xa[j][k] = v ? reinterpret_cast<const f64x2*>(p.Xt + (size_t)k * p.Npad)[idx] : f64x2{0.0, 0.0};
-        aa[j] = v ? reinterpret_cast<const f64x2*>(p.alpha)[idx] : f64x2{0.0, 0.0};
-    }
-    if (tid < ALABI_MAX_DIM) {
-        consts_s[0][tid] = (tid < p.d) ? p.consts[tid] : 0.0;
-        consts_s[1][tid] = (tid < p.d) ? p.consts[ALABI_MAX_DIM + tid] : 0.0;
-        consts_s[2][tid] = (tid < p.d) ? p.consts[2 * ALABI_MAX_DIM + tid] : 0.0;
-        consts_s[3][tid] = (tid < p.d) ? p.consts[3 * ALABI_MAX_DIM + tid] : 0.0;
-        consts_s[4][tid] = (tid < p.d) ? p.consts[4 * ALABI_MAX_DIM + tid] : 0.0;
-    }
-    if (tid < 32) scratch[tid >> 4][tid & 15] = 0.0;
-    if (tid < 4) ctl_s[tid >> 1][tid & 1] = 0;
-    // proposal records of steps 0, 1 into the ring, step 2 in flight (lane l < 4 of the last wave loads word l)
-    const unsigned long long* packed = p.rec.packed;
-    auto record_load = [&](int t) -> unsigned long long {
-        if (t >= p.K || lane >= 4) return 0ull;
-        const size_t rp = ((size_t)t * E + e) * p.W + g;
-        return packed[4 * rp + lane];
-    };
-    unsigned long long pend = 0;
-    if (service) {
-        for (int i = 0; i < 2; ++i) {
-            const unsigned long long v = record_load(i);
-            if (lane < 4) rec_s[i][lane] = v;
-        }
-        pend = record_load(2);
-    }
-    __syncthreads();
-    int rnd = 0;                                          // rounds so far: parity selects the LDS proposal buffer
-    if (!comm) {
-        // ---- compute and record waves: serve rounds until the kernel ends
-        for (int t = 0; t < p.K; ++t) {
-            bool fetched = false;
-            for (;;) {
-                const int par = rnd & 1;
-                __syncthreads();                           // barrier A: wave 0 has published a proposal, or closed the item
-                ++rnd;
-                if (ctl_s[0][1]) return;
-                if (ctl_s[par][0]) break;                  // item finished
-                double qraw[D];
-#pragma unroll
-                for (int k = 0; k < D; ++k) qraw[k] = qs_s[par][k];
-                // qs_s[par][63]: 0 = proposal outside the box (no sum), 1 + slot = sum slot the partials go to
-                const int tagw = __builtin_amdgcn_readfirstlane(__double2hiint(qs_s[par][63]));
-                const int cin = tagw != 0, slot = (tagw >> 30) & 1;   // high word of 1.0 = 0x3FF00000, of 2.0 = 0x40000000: bit 30
-                if (compute && cin) {
-                    double q[D];
-#pragma unroll
-                    for (int k = 0; k < D; ++k)
-                        q[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(qraw[k])),
-                                                __builtin_amdgcn_readfirstlane(__double2loint(qraw[k])));
-                    double acc = 0.0;
-#pragma unroll
-                    for (int j = 0; j < PPT; ++j) {
-                        double r2a = 0.0, r2b = 0.0;
-#pragma unroll
-                        for (int k = 0; k < D; ++k) {
-                            const double da = xa[j][k].x - q[k], db = xa[j][k].y - q[k];
-                            r2a = fma(da, da, r2a);
-                            r2b = fma(db, db, r2b);
-                        }
-                        acc = (j == 0) ? aa[j].x * radial<GENERIC>(r2a, p.kf) : fma(aa[j].x, radial<GENERIC>(r2a, p.kf), acc);
-                        acc = fma(aa[j].y, radial<GENERIC>(r2b, p.kf), acc);
-                        if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-                    }
-                    const double wsum = wave_sum_dpp(acc);
-                    if (lane == 63) scratch[slot][wv - 1] = wsum;
-                }
-                if (service) {
-                    // publish the proposal of this round: a partner waiting for this walker's decision can already evaluate
-                    // "accepted" (p.prop == nullptr: no publishing).  Later rounds of the item overwrite it.
-                    if (p.prop && lane < p.d) {
-                        const int w_pub = (int)(unsigned)(rec_s[t & 3][0] & 0xffffffffull);
-                        st_sc1(p.prop + ((size_t)(t + 1) * WT + w_pub) * p.d + lane,
-                               (unsigned long long)__double_as_longlong(qs_s[par][32 + lane]));
-                    }
-                    if (!fetched) {                        // once per item: ring slot t+2, issue t+3
-                        if (lane < 4) rec_s[(t + 2) & 3][lane] = pend;
-                        pend = record_load(t + 3);
-                        fetched = true;
-                    }
-                }
-                __syncthreads();                           // barrier B: the partial sums are in LDS
-            }
-        }
-        return;
-    }
-    // ---- wave 0: the dependency chain.  Lanes 0..31 watch the walker's own row, lanes 32..63 the partner's row
-    // (word hl of the row in lane hl: coordinates, logp, acceptance flag), so ONE load instruction looks at both.
-    // Sums are memoised in two slots, each tagged with the coordinates it was computed from; the accept test takes the slot
-    // whose tag equals the REAL rows, whatever those turn out to be.  Slot 0: the best rows known (real, else the previous
-    // version: right whenever the pending update is rejected); slot 1: the partner's PUBLISHED proposal in place of its row
-    // (right whenever its pending update is accepted).
-    const int hl = lane & 31, grp = lane >> 5;
-    const bool need = hl <= p.d + 1, isc = hl < p.d;       // words watched; coordinate words (what a sum depends on)
-    const int wl = need ? hl : 0;                          // spare lanes re-read word 0 (keeps every lane's address valid)
-    const double il_r = consts_s[0][lane], lo_r = consts_s[1][lane], hi_r = consts_s[2][lane];
-    for (int t = 0; t < p.K; ++t) {
-        const unsigned long long* rs = rec_s[t & 3];
-        const unsigned long long ids = rs[0];
-        const int w = (int)(unsigned)(ids & 0xffffffffull), cw = (int)(unsigned)(ids >> 32);
-        const double zz = __longlong_as_double((long long)rs[1]);
-        const double lnfac = __longlong_as_double((long long)rs[2]), lnu = __longlong_as_double((long long)rs[3]);
-        const int vrow = t + (grp ? split : 0);            // own row: version t; partner row: version t (+1: its half went first)
-        const unsigned long long* pa = p.hist + ((size_t)vrow * WT + (grp ? cw : w)) * row + wl;
-        const bool has_prev = vrow > 0;                    // is there a previous version to stand in?
-        const unsigned long long* pb = has_prev ? pa - (size_t)WT * row : pa;
-        // the partner's published proposal for the update that produces version vrow (partner lanes, coordinate words)
-        const bool use_prop = p.prop != nullptr && grp == 1 && isc && has_prev;
-        const unsigned long long* pp = use_prop ? p.prop + ((size_t)vrow * WT + cw) * p.d + hl : pa;
-        unsigned long long real = ALABI_HIST_EMPTY, prev = ALABI_HIST_EMPTY, prop = ALABI_HIST_EMPTY;
-        bool own_real = false, par_real = false;
-        unsigned long long tag0 = ALABI_HIST_EMPTY, tag1 = ALABI_HIST_EMPTY;   // rows the two slots were computed from
-        bool val0 = false, val1 = false;
-        int in0 = 0, in1 = 0, spins = 0;
-        double q0v = 0.0, q1v = 0.0;                       // lane k < d: coordinate k of the slot's proposal
-        int n_rounds = 0, n_spec_rounds = 0, last_spec = 0;
-#ifdef ALABI_SPEC_PROF
-        long long t_det_own = 0, t_det_par = 0, t_round = 0;
-        const long long t_item0 = __builtin_amdgcn_s_memrealtime();
-#endif
-        auto merge = [&](unsigned long long v) {
-            if (real == ALABI_HIST_EMPTY) real = v;
-            const unsigned long long miss = __ballot(need && real == ALABI_HIST_EMPTY);
-#ifdef ALABI_SPEC_PROF
-            const bool o_ = own_real, p_ = par_real;
-#endif
-            own_real = (miss & 0xffffffffull) == 0ull;
-            par_real = (miss >> 32) == 0ull;
-#ifdef ALABI_SPEC_PROF
-            if (own_real && !o_) t_det_own = __builtin_amdgcn_s_memrealtime();
-            if (par_real && !p_) t_det_par = __builtin_amdgcn_s_memrealtime();
-#endif
-        };
-        // does a slot's tag equal the rows `rows` on every coordinate word of both groups?
-        auto same = [&](unsigned long long tag, unsigned long long rows) { return __ballot(isc && tag != rows) == 0ull; };
-        merge(ld_sc1(pa));
-        int fin = -1;                                      // slot that holds the sum of the real proposal
-        for (;;) {
-            // (1) everything known: take the matching slot, or compute it now
-            if (own_real && par_real) {
-                if (val0 && same(tag0, real)) { fin = 0; break; }
-                if (val1 && same(tag1, real)) { fin = 1; break; }
-            }
-            // (2) targets, in order of likelihood: [best rows], then [partner replaced by its published proposal]
-            const bool grp_real = grp ? par_real : own_real;
-            if (!grp_real && has_prev && prev == ALABI_HIST_EMPTY) prev = ld_sc1(pb);
-            const unsigned long long best = grp_real ? real : prev;
-            const bool best_av = __ballot(need && !grp_real && (!has_prev || prev == ALABI_HIST_EMPTY)) == 0ull;
-            int target = -1;                               // 0: best rows -> slot 0; 1: proposal hypothesis -> slot 1
-            unsigned long long rows = best;
-            if (best_av && !(val0 && same(tag0, best)) && !(val1 && same(tag1, best))) target = 0;
-            if (target < 0 && best_av && !par_real && p.prop != nullptr) {
-                if (use_prop) prop = ld_sc1(pp);
-                const bool prop_av = __ballot(use_prop && prop == ALABI_HIST_EMPTY) == 0ull && (t + split > 0);
-                if (prop_av) {
-                    rows = use_prop ? prop : best;         // partner coordinates from the proposal, own rows as in `best`
-                    if (!same(best, rows) && !(val1 && same(tag1, rows)) && !(val0 && same(tag0, rows))) target = 1;
-                }
-            }
-            if (target < 0) {
-                // nothing to compute: look at the missing real rows again
-                merge(ld_sc1(pa));
-                if ((spins += 1) > p.spin_limit ||
-                    ((spins & 63) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                    if (lane == 0) { ctl_s[0][1] = 1; __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                    __syncthreads();                       // releases the other waves at barrier A: they see the abort word
-                    return;
-                }
-                continue;
-            }
-            // (3) a round: proposal from `rows`, kernel sum by the compute waves into slot `target`
-            const int par = rnd & 1;
-            ++n_rounds; last_spec = !(own_real && par_real); n_spec_rounds += last_spec;
-            const double sv = __longlong_as_double((long long)rows);
-            const double cv = __shfl(sv, lane + 32, 64);   // lane k < 32: word k of the partner's row
-            int inb = 1;
-            double qs = 0.0, qv = 0.0;
-            if (lane < p.d) {
-                qv = cv - (cv - sv) * zz;
-                inb = (qv > lo_r) && (qv < hi_r);
-                qs = qv * il_r;
-            }
-            const int all_in = __all(inb);
-            if (lane < D) qs_s[par][lane] = qs;
-            if (lane < p.d) qs_s[par][32 + lane] = qv;     // unscaled: what the record wave publishes
-            if (lane == 63) qs_s[par][63] = all_in ? (target ? 2.0 : 1.0) : 0.0;
-            if (lane == 0) ctl_s[par][0] = 0;
-            if (target == 0) { tag0 = rows; q0v = qv; in0 = all_in; val0 = true; }
-            else { tag1 = rows; q1v = qv; in1 = all_in; val1 = true; }
-#ifdef ALABI_SPEC_PROF
-            const long long tr0 = __builtin_amdgcn_s_memrealtime();
-#endif
-            __syncthreads();                               // barrier A
-            ++rnd;
-            if (!(own_real && par_real)) merge(ld_sc1(pa));   // while the sum runs: one more look
-            __syncthreads();                               // barrier B
-#ifdef ALABI_SPEC_PROF
-            t_round += __builtin_amdgcn_s_memrealtime() - tr0;
-#endif
-        }
-        // accept test on the sum of the real proposal, publish the new row, close the item for the other waves
-        {
-            const double sv = __longlong_as_double((long long)real);        // lanes < 32: the own row (lane d: its logp)
-            const double qv = fin ? q1v : q0v;
-            const int all_in = fin ? in1 : in0;
-            double prior_q = 0.0;
-            if (p.has_prior) prior_q = normal_prior_sum(consts_s[3], consts_s[4], lane, p.d, qv) + p.prior_const;
-            double lp_new = -INFINITY;
-            if (all_in) lp_new = fma(p.amp, wave_partials_tree(scratch[fin], nwc), p.mean) + prior_q;
-            const double lp_old = lane_bcast(sv, p.d);
-            const int acc_flag = (lnfac + lp_new - lp_old > lnu) ? 1 : 0;
-            const double outv = (lane < p.d) ? (acc_flag ? qv : sv) : (acc_flag ? lp_new : lp_old);
-            const unsigned long long outw = (lane <= p.d) ? (unsigned long long)__double_as_longlong(outv)
-                                                          : (unsigned long long)acc_flag;
-            if (lane <= p.d + 1) st_sc1(p.hist + ((size_t)(t + 1) * WT + w) * row + lane, outw);
-#ifdef ALABI_SPEC_PROF
-            const long long t_store = __builtin_amdgcn_s_memrealtime();
-            unsigned long long* tsb = reinterpret_cast<unsigned long long*>(p.dbg) + 16 * 4096;   // publish times [version][walker]
-            if (p.dbg && lane == 0) st_sc1(tsb + (size_t)(t + 1) * WT + w, (unsigned long long)t_store);
-#endif
-            if (lane == 0) ctl_s[rnd & 1][0] = 1;
-            __syncthreads();                               // barrier A of a closing round
-            ++rnd;
-            if (p.dbg && lane == 0) {                      // [0] items [1] rounds [2] guessed rounds [3] items finished on a guess [4] polls
-                long long* c = p.dbg + 16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
-                c[0] += 1; c[1] += n_rounds; c[2] += n_spec_rounds; c[3] += last_spec; c[4] += spins; c[12] += fin;
-#ifdef ALABI_SPEC_PROF
-                const long long ts_o = t > 0 ? (long long)ld_sc1(tsb + (size_t)t * WT + w) : 0;
-                const long long ts_p = t + split > 0 ? (long long)ld_sc1(tsb + (size_t)(t + split) * WT + cw) : 0;
-                const bool par_last = t_det_par >= t_det_own;
-                const long long t_last = par_last ? t_det_par : t_det_own, ts_last = par_last ? ts_p : ts_o;
-                if (ts_last > 0 && t_last > 0) { c[5] += t_last - ts_last; c[6] += 1; }
-                if (last_spec) c[7] += t_store - t_last; else c[8] += t_store - t_last;
-                c[9] += t_round; c[10] += __builtin_amdgcn_s_memrealtime() - t_item0; c[11] += par_last;
-#endif
-            }
-        }
-    }
-}
-
 // hist[0] <- (coords, logp); and back: (coords, logp) <- hist[K]
 __global__ void __launch_bounds__(256)
 ens_hist_fill_kernel(unsigned long long* __restrict__ h, size_t n) {
@@ -1175,13 +869,8 @@ bool ens_stream_fits(const alabi_ens* e) { return ens_stream_ppt(e) > 0; }
         default: return ALABI_BAD_ARGUMENT;                           \
     }
 #define ALABI_STREAM_LAUNCH(PPT_, TMAX_)                                                                          \
-    if (spec) {                                                                                                   \
-        ALABI_STREAM_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type,                                          \
-            hipLaunchKernelGGL((ens_spec_kernel<D, PPT_, TMAX_, GENERIC>), dim3(e->W, e->E), dim3(T + 128), 0, s, a))) \
-    } else {                                                                                                      \
-        ALABI_STREAM_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type,                                          \
-            hipLaunchKernelGGL((ens_stream_kernel<D, PPT_, TMAX_, GENERIC>), dim3(e->stream_grid, e->E), dim3(T + 128), 0, s, a))) \
-    }
+    ALABI_STREAM_DISPATCH_DIM(db, ALABI_DISPATCH_KERNEL(gp->kf.type,                                              \
+        hipLaunchKernelGGL((ens_stream_kernel<D, PPT_, TMAX_, GENERIC>), dim3(e->stream_grid, e->E), dim3(T + 128), 0, s, a)))
 
 // Version history around a persistent launch of K steps: rows 1..K <- sentinel (`fill`: when the rows are polled), row 0 <- (coords, logp) before it;
 // (coords, logp) <- row K, chain / counters <- rows 1..K after it.  Shared by ens_stream_kernel and ens_group_kernel.
@@ -1208,7 +897,6 @@ int launch_ens_hist_epilogue(alabi_ens* e, double* coords, double* logp, int K, 
 int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
                       long long* n_accept, hipStream_t s) {
     alabi_gp* gp = e->gp;
-    const int WT = e->W * e->E;
     const int n0 = (e->W + 1) / 2;
     { const int st0 = launch_ens_hist_prologue(e, coords, logp, K, true, s); if (st0 != ALABI_OK) return st0; }
     StreamArgs a{};
@@ -1219,40 +907,11 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
     if (const char* env = getenv("ALABI_ENS_SPIN_LIMIT")) { const int v = atoi(env); if (v > 0) a.spin_limit = v; }   // tests: force a time-out
     a.amp = e->lp_scale * exp(gp->log_amp); a.mean = fma(e->lp_scale, gp->mean, e->lp_shift); a.kf = gp->kf;
     a.has_prior = e->has_prior; a.prior_const = e->prior_const;
-    if (const char* env = getenv("ALABI_ENS_POLL_SLEEP")) a.poll_sleep = atoi(env);
     const int db = dim_bucket(e->d);
     // lanes x pairs-per-lane cover Npad/2 point pairs; the launch-per-half-step kernel's lane -> point map (and so its
     // summation order) is reproduced exactly because both run with e->threads compute lanes.
     const int T = e->threads, ppt = ens_stream_ppt(e);
-    // one workgroup per list position of BOTH halves when they all fit on the chip: the speculative kernel
-    const char* spec_env = getenv("ALABI_ENS_SPEC");
-    // Opt-in (ALABI_ENS_SPEC=1): measured on MI355X at the headline size it is bit-identical but not faster than
-    // ens_stream_kernel (2.09 vs 1.99 us per half step: 40 % of the proposals finish on a guess, the publish -> detect
-    // hand-off of 1.09 us stays on the chain either way; with published proposals as a second hypothesis
-    // (ALABI_ENS_SPEC_PROP=1) 59 % finish on a guess but the extra rounds keep wave 0 at barrier B: 2.45 us; DESIGN.md
-    // section 4).
-    const bool spec = e->spec_ok && spec_env && spec_env[0] == '1';
-    e->last_path = spec ? 2 : 1;
-    if (spec && !e->prop && e->d <= 30 && getenv("ALABI_ENS_SPEC_PROP") && getenv("ALABI_ENS_SPEC_PROP")[0] == '1') {
-        if (hipMalloc(&e->prop, ((size_t)e->chunk_cap + 1) * WT * e->d * sizeof(unsigned long long)) != hipSuccess) {
-            (void)hipGetLastError(); e->prop = nullptr;
-        }
-    }
-    if (spec && e->prop) {
-        const char* pe_ = getenv("ALABI_ENS_SPEC_PROP");   // second hypothesis (published proposals): measured slower, opt-in
-        if (pe_ && pe_[0] == '1' && e->d <= 30) {
-            a.prop = e->prop;
-            hipLaunchKernelGGL(ens_hist_fill_kernel, dim3(1024), dim3(256), 0, s, e->prop, (size_t)(K + 1) * WT * e->d);
-        }
-    }
-    static long long* dbg_buf = nullptr;
-    const char* dbg_env = getenv("ALABI_SPEC_DBG");
-    if (spec && dbg_env && dbg_env[0] == '1') {
-        const size_t dbg_bytes = 8 * 16 * 4096 + 8 * (size_t)(e->chunk_cap + 1) * e->W * e->E;
-        if (!dbg_buf) (void)hipMalloc(&dbg_buf, 8 * 16 * 4096 + 8 * (size_t)1025 * 4096);
-        (void)hipMemsetAsync(dbg_buf, 0, dbg_bytes, s);
-        a.dbg = dbg_buf;
-    }
+    e->last_path = 1;
     if (T == 256) {
         if (ppt == 1) { ALABI_STREAM_LAUNCH(1, 384); }
         else if (ppt == 2) { ALABI_STREAM_LAUNCH(2, 384); }
@@ -1264,24 +923,6 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
         else if (ppt == 2) { ALABI_STREAM_LAUNCH(2, 640); }
         else return ALABI_BAD_ARGUMENT;
     } else return ALABI_BAD_ARGUMENT;
-    if (a.dbg) {
-        std::vector<long long> h(16 * (size_t)e->W * e->E);
-        (void)hipMemcpyAsync(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost, s);
-        (void)hipStreamSynchronize(s);
-        long long tot[12] = {0}, s0[2] = {0, 0}, s1[2] = {0, 0}, h_prop_fin = 0;
-        for (size_t i = 0; i < h.size(); i += 16) { for (int k = 0; k < 12; ++k) tot[k] += h[i + k]; h_prop_fin += h[i + 12]; }
-        for (int g = 0; g < e->W; ++g) { long long* t2 = g < n0 ? s0 : s1; t2[0] += h[16 * g + 3]; t2[1] += h[16 * g]; }
-        if (tot[6] > 0)
-            fprintf(stderr, "[ens_spec_kernel prof] publish->detect of the last row %.3f us (%lld samples, partner last %.2f); last detection->store: "
-                            "on a guess %.3f us, otherwise %.3f us; rounds %.3f us/item; item %.3f us\n", 0.01 * tot[5] / tot[6], tot[6],
-                    (double)tot[11] / tot[0], 0.01 * tot[7] / (tot[3] ? tot[3] : 1), 0.01 * tot[8] / ((tot[0] - tot[3]) ? (tot[0] - tot[3]) : 1),
-                    0.01 * tot[9] / tot[0], 0.01 * tot[10] / tot[0]);
-        fprintf(stderr, "[ens_spec_kernel] K=%d items %lld rounds/item %.3f guessed rounds/item %.3f finished-on-a-guess %.3f "
-                        "(set 0: %.3f, set 1: %.3f) polls/item %.2f\n", K, tot[0], (double)tot[1] / tot[0], (double)tot[2] / tot[0],
-                (double)tot[3] / tot[0], s0[1] ? (double)s0[0] / s0[1] : 0.0, s1[1] ? (double)s1[0] / s1[1] : 0.0,
-                (double)tot[4] / tot[0]);
-        fprintf(stderr, "[ens_spec_kernel] finished on the proposal slot: %.3f of the items\n", (double)h_prop_fin / tot[0]);
-    }
     ALABI_LAUNCH_CHECK();
     return launch_ens_hist_epilogue(e, coords, logp, K, thin_by, chain, chain_logp, n_accept, s);
 }

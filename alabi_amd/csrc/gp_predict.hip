@@ -20,14 +20,6 @@
 //                  re-read through L2.  N^2 flops per query (MFMA bound), L streamed once per
 //                  64-query tile.
 #include <cstdlib>
-// Compile-time ablation switches of the wave-specialised variance kernel (timing only, results are wrong when set):
-// -DALABI_PV_NO_MFMA=1 removes the matrix-core work, -DALABI_PV_NO_LOADS=1 the steady-state global loads.
-#ifndef ALABI_PV_NO_MFMA
-#define ALABI_PV_NO_MFMA 0
-#endif
-#ifndef ALABI_PV_NO_LOADS
-#define ALABI_PV_NO_LOADS 0
-#endif
 #include "gp_device.hpp"
 
 namespace alabi {
@@ -363,7 +355,7 @@ ws_produce_tile(const double* L_, const double* dinv_, int Npad, const double* V
             if (diag) __syncthreads();     /* the consumers' mid-stage barrier */                             \
             ALABI_WS_TO_LDS(NSET, nbuf, true)                                                                 \
             if (k3 < nb - 1 || s3 < k3) ALABI_WS_ADVANCE(k3, s3)                                              \
-            if (!ALABI_PV_NO_LOADS) ALABI_WS_ISSUE(NSET, k3, s3)                                              \
+            ALABI_WS_ISSUE(NSET, k3, s3)                                                                      \
             ++b;                                                                                              \
             ALABI_WS_ADVANCE(kb, sj)                                                                          \
         }
@@ -412,7 +404,7 @@ ws_consume_tile(int Npad, double* V_, int kb0) {
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         const double bb = ws_Vs[buf][4 * ks + lk][16 * n + lr];
-                        if (!ALABI_PV_NO_MFMA) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[n], 0, 0, 0);
                     }
                 }
                 continue;
@@ -1199,8 +1191,7 @@ int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, 
         if (dev_alloc_cached((void**)&gp->ws, need, &got) != (int)hipSuccess) return ALABI_HIP_ERROR;
         gp->ws_bytes = got;
     }
-    int split = 0;   // ablation knob for tools/prof_predict.py only (results are wrong unless 0)
-    if (const char* env = getenv("ALABI_PV_ABLATE")) split = atoi(env);
+    const int split = 0;   // a run-time zero the kernel tests against (see its first comment): keeps two code regions apart
     ALABI_DISPATCH_DIM(db, hipLaunchKernelGGL(predict_var_kernel<D>, dim3(grid), dim3(256), 0, s, gp->L, gp->dinv, gp->Xt,
                                               gp->alpha, gp->N, gp->Npad, Xs, gp->d, M, gp->inv_len, amp,
                                               gp->mean, gp->ws, mu, var, split, gp->kf));

@@ -301,8 +301,8 @@ class EnsembleSampler:
         _lib.check(st, "alabi_ens_run")
         path = C.c_int(0)
         _lib.lib().alabi_ens_last_path(self._ens, C.byref(path))
-        self.last_path = {1: "stream", 2: "stream", 3: "group"}.get(path.value, "launch-per-half-step")
-        self.last_stream_kernel = {1: "ens_stream_kernel", 2: "ens_spec_kernel", 3: "ens_group_kernel"}.get(path.value)
+        self.last_path = {1: "stream", 3: "group"}.get(path.value, "launch-per-half-step")
+        self.last_stream_kernel = {1: "ens_stream_kernel", 3: "ens_group_kernel"}.get(path.value)
         self._stream.synchronize()
         torch.cuda.current_stream().wait_stream(self._stream)
         self.last_run_seconds = time.perf_counter() - t0

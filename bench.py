@@ -201,6 +201,64 @@ def parity_gate(cfg, gp, y_dev, cpu_chain, args):
     return gate
 
 
+def config_extras():
+    """BASELINE.json's other configurations, each on its own workload, so that the driver's line (not only profiles/) holds
+    their numbers: ensemble throughput of C1, C2, C4 and the C5-sized ensemble (N=10000, d=20, 2048 walkers) with the chain
+    stored, and the C5 BAPE scan over 10^6 candidates.  A few hundred steps each: ~10 s in all."""
+    import torch
+    from alabi_amd import EnsembleSampler, HipGP
+    from alabi_amd.utility import utility_scan
+    from alabi_amd.workloads import make_config
+    res = {}
+    for name, steps in (("C1", 2048), ("C2", 2048), ("C4", 1024), ("C5", 512)):
+        try:
+            cfg = make_config(name)
+            h = cfg["hyper"]
+            gp = HipGP(cfg["d"], h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"])
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            gp.compute(cfg["X"]); torch.cuda.synchronize()
+            fit_ms = 1e3 * (time.perf_counter() - t0)
+            s = EnsembleSampler(cfg["W"], cfg["d"], gp, cfg["y"], cfg["bounds"], seed=5)
+            s.run_mcmc(cfg["p0"], 32, store=False)
+            torch.cuda.synchronize()
+            best = None
+            for _ in range(2):
+                ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+                s._stream.wait_stream(torch.cuda.current_stream())
+                ev0.record(s._stream)
+                s.run_mcmc(None, steps, store=True)
+                ev1.record(s._stream); torch.cuda.synchronize()
+                ms = ev0.elapsed_time(ev1)
+                best = ms if best is None else min(best, ms)
+                s.reset()
+            entry = {"N_train": cfg["N"], "d": cfg["d"], "walkers": cfg["W"], "steps": steps, "path": s.last_path,
+                     "kernel": s.last_stream_kernel or "ens_half_kernel / ens_half_multi_kernel",
+                     "samples_per_s": cfg["W"] * steps / (best * 1e-3), "us_per_half_step": 1e3 * best / (2 * steps),
+                     "fit_ms_first_call": fit_ms, "acceptance_fraction": None}
+            # algorithmic fp64 work of the kernel sums: W/2 proposals x N points x (2d + 3) per half step
+            entry["tflops"] = (cfg["W"] / 2.0) * cfg["N"] * (2 * cfg["d"] + 3) / (entry["us_per_half_step"] * 1e-6) / 1e12
+            entry["roofline_frac_fp64"] = entry["tflops"] / FP64_PEAK_TFLOPS
+            if name == "C5":
+                gen = torch.Generator(device="cuda"); gen.manual_seed(6)
+                lo = torch.as_tensor(cfg["bounds"][:, 0], device="cuda"); hi = torch.as_tensor(cfg["bounds"][:, 1], device="cuda")
+                cand = lo + (hi - lo) * torch.rand((1_000_000, cfg["d"]), dtype=torch.float64, device="cuda", generator=gen)
+                utility_scan(gp, cfg["y"], cand[:4096], cfg["bounds"], "bape")            # builds L^-1 once (as active_train does)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                utility_scan(gp, cfg["y"], cand, cfg["bounds"], "bape")
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                entry["bape_scan_1e6_candidates_s"] = dt
+                entry["bape_scan_candidates_per_s"] = 1e6 / dt
+                entry["bape_scan_tflops"] = 1e6 * (cfg["N"] ** 2 + cfg["N"] * (2 * cfg["d"] + 3)) / dt / 1e12
+                del cand
+            res[name] = entry
+            del s, gp
+            torch.cuda.empty_cache()
+        except Exception as ex:  # noqa: BLE001  (a side measurement must never cost the headline line)
+            res[name] = {"error": repr(ex)[:300]}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -388,6 +446,11 @@ def main():
             lanes = 256 if npad // 2 <= 1024 else 1024            # alabi_ens_create's choice (api.hip)
             lanes = int(os.environ.get("ALABI_ENS_THREADS", lanes))
             kernel_name = f"ens_stream_kernel<{d},{-(-(npad // 2) // lanes)},{lanes + 128}>"
+        elif path == "group":
+            chunk = min(args.mcmc_steps, 1024)
+            launches_per_step = -(-args.mcmc_steps // chunk)
+            flops_per_launch = 2.0 * chunk * n_prop * N * (2 * d + 3)
+            kernel_name = f"ens_group_kernel<{(d + 2 + 3) // 4},...>"
         else:
             flops_per_launch = n_prop * N * (2 * d + 3)
             kernel_name = f"ens_half_kernel<{d}>"
@@ -464,6 +527,10 @@ def main():
                                            "frac": ch_tf / FP64_PEAK_TFLOPS, "kernel": "chol_tasks_kernel (one launch, tile tasks with slab-wise hand-over; N^3/3 flops, assembly included in the time)",
                                            "counters": pmc_summary("chol_tasks_kernel", "mean"),
                                            "note": "N=2000 is latency-bound on the chain of 31 diagonal factorisations; N=10000: 30 TFLOP/s, N=16000: 44 TFLOP/s on the panel path (DESIGN.md par. 7, profiles/r02_cholesky_*)"}
+            if args.config == "C3" and not shard:
+                t_cfg = time.perf_counter()
+                extras["configs"] = config_extras()
+                extras["configs_wall_s"] = time.perf_counter() - t_cfg
             out["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             out["parity_gate"] = parity_gate(cfg, gp, y_dev, cpu_chain, args)

@@ -170,8 +170,9 @@ int alabi_ens_set_logp_map(alabi_ens* ens, int kind);
 /* Enable / disable the persistent dataflow kernel for alabi_ens_run on this handle (default: enabled when the
  * ensemble fits one workgroup per CU).  Returns ALABI_BAD_ARGUMENT when enabling is impossible. */
 int alabi_ens_set_stream(alabi_ens* ens, int enabled);
-/* Which path the last alabi_ens_run took: 1 = persistent dataflow kernel, 2 = its speculative variant (one workgroup per
- * list position of both halves, W * n_ensembles <= #CUs), 0 = one launch per half step. */
+/* Which path the last alabi_ens_run took: 1 = persistent dataflow kernel with the training set in one workgroup's
+ * registers (ens_stream_kernel: N <= 2048, small d), 3 = persistent group kernel (ens_group_kernel: training set
+ * partitioned over groups of workgroups, kernel sums on the matrix cores; d <= 30), 0 = one launch per half step. */
 int alabi_ens_last_path(alabi_ens* ens, int* path /* host */);
 
 /* log-probability of every walker (surrogate mean + box prior): coords [E*W,d] -> logp [E*W]. */

@@ -207,30 +207,24 @@ def test_stream_kernel_equals_launch_per_half_step(setup, monkeypatch):
         assert np.array_equal(a.get_chain(), b.get_chain())
 
 
-def test_speculative_kernel_equals_the_other_paths(setup, monkeypatch):
-    """W * E <= #CUs: ens_spec_kernel (one workgroup per list position of both halves, early evaluation from stand-in
-    rows) against ens_stream_kernel and the launch-per-half-step path -- bit-identical chains whatever was guessed."""
+def test_persistent_kernel_equals_the_launch_per_half_step_path(setup, monkeypatch):
+    """ens_stream_kernel against the launch-per-half-step kernels at several ensemble shapes (one or several ensembles per
+    launch, odd walker counts, thinning): bit-identical chains, log-probabilities and acceptance counters."""
     torch, g, o, y, bounds = setup
     from alabi_amd import EnsembleSampler
     for W, E, nsteps, thin in ((256, 1, 1500, 1), (64, 4, 400, 3), (37, 2, 257, 1), (10, 1, 1100, 1)):
         p0 = np.random.RandomState(W + E).uniform(-2.5, 2.5, (W * E, 5))
         runs = {}
-        for tag, stream, spec in (("spec", "1", "1"), ("spec+prop", "1", "1"), ("stream", "1", "0"), ("half", "0", "0")):
+        for tag, stream in (("stream", "1"), ("half", "0")):
             monkeypatch.setenv("ALABI_ENS_STREAM", stream)
-            monkeypatch.setenv("ALABI_ENS_SPEC", spec)
-            monkeypatch.setenv("ALABI_ENS_SPEC_PROP", "1" if tag == "spec+prop" else "0")
             s = EnsembleSampler(W, 5, g, y, bounds, seed=17, n_ensembles=E)
             s.run_mcmc(p0, nsteps, thin_by=thin)
             assert getattr(s, "stream_fallbacks", 0) == 0
-            assert s.last_stream_kernel == {"spec": "ens_spec_kernel", "spec+prop": "ens_spec_kernel",
-                                            "stream": "ens_stream_kernel", "half": None}[tag]
+            assert s.last_stream_kernel == {"stream": "ens_stream_kernel", "half": None}[tag]
             runs[tag] = (s.get_chain(), s.get_log_prob(), s._naccept.cpu().numpy().copy())
-        for tag in ("spec+prop", "stream", "half"):
-            assert np.array_equal(runs["spec"][0], runs[tag][0]), (W, E, tag)
-            assert np.array_equal(runs["spec"][1], runs[tag][1])
-            assert np.array_equal(runs["spec"][2], runs[tag][2])
-    monkeypatch.delenv("ALABI_ENS_SPEC")
-    monkeypatch.delenv("ALABI_ENS_SPEC_PROP")
+        assert np.array_equal(runs["stream"][0], runs["half"][0]), (W, E)
+        assert np.array_equal(runs["stream"][1], runs["half"][1])
+        assert np.array_equal(runs["stream"][2], runs["half"][2])
 
 
 def test_persistent_kernel_timeout_falls_back(monkeypatch):
