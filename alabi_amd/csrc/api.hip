@@ -135,6 +135,7 @@ int alabi_gp_destroy(alabi_gp* gp) {
     if (gp->Xt) (void)hipFree(gp->Xt);
     if (gp->Xa) (void)hipFree(gp->Xa);
     if (gp->xa_centre) (void)hipFree(gp->xa_centre);
+    if (gp->host_status) (void)hipHostFree(gp->host_status);
     if (gp->y) (void)hipFree(gp->y);
     if (gp->alpha) (void)hipFree(gp->alpha);
     if (gp->dinv) (void)hipFree(gp->dinv);
@@ -181,27 +182,28 @@ int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream) {
     gp->computed = false; gp->has_alpha = false; gp->gen++;
     int st;
     if ((st = launch_prepare_inputs(gp, X, N, s)) != ALABI_OK) return st;
-    if ((st = launch_assemble(gp, s)) != ALABI_OK) return st;
-    // up to 64 block columns: the task-queue factorisation (one launch); a wait that runs out there is remembered for a while
+    // 16..160 block columns: the task-queue factorisation (one launch); a wait that runs out there is remembered for a while
     static std::atomic<int> tasks_penalty{0};
-    int queued = 0;
+    int queued = 0, ctl_ints = 0;
     if (tasks_penalty.load(std::memory_order_relaxed) > 0) tasks_penalty.fetch_sub(1, std::memory_order_relaxed);
-    else if ((st = launch_cholesky_tasks(gp, s, &queued)) != ALABI_OK) return st;
+    else if ((st = cholesky_tasks_prepare(gp, s, &ctl_ints)) != ALABI_OK) return st;
+    if ((st = launch_assemble(gp, s, ctl_ints)) != ALABI_OK) return st;   // also clears the status word and the queue's control words
+    if (ctl_ints > 0 && (st = launch_cholesky_tasks(gp, s, &queued)) != ALABI_OK) return st;
     if (!queued && (st = launch_cholesky(gp, s)) != ALABI_OK) return st;
-    int info = 0;
-    ALABI_HIP_CHECK(hipMemcpyAsync(&info, gp->info, sizeof(int), hipMemcpyDeviceToHost, s));
-    if (queued) {
-        int timed_out = 0;
-        ALABI_HIP_CHECK(hipMemcpyAsync(&timed_out, gp->chol_ctl + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-        ALABI_HIP_CHECK(hipStreamSynchronize(s));
-        if (timed_out) {                                   // undefined matrix state: assemble and factorise again, step by step
-            tasks_penalty.store(64, std::memory_order_relaxed);
-            if ((st = launch_assemble(gp, s)) != ALABI_OK) return st;
-            if ((st = launch_cholesky(gp, s)) != ALABI_OK) return st;
-            ALABI_HIP_CHECK(hipMemcpyAsync(&info, gp->info, sizeof(int), hipMemcpyDeviceToHost, s));
-        }
-    }
+    // one read-back of (pivot status, queue time-out) into pinned memory, one synchronisation
+    if (!gp->host_status) ALABI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&gp->host_status), 2 * sizeof(int), hipHostMallocDefault));
+    gp->host_status[1] = 0;
+    ALABI_HIP_CHECK(hipMemcpyAsync(&gp->host_status[0], gp->info, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (queued) ALABI_HIP_CHECK(hipMemcpyAsync(&gp->host_status[1], gp->chol_ctl + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     ALABI_HIP_CHECK(hipStreamSynchronize(s));
+    if (queued && gp->host_status[1]) {                     // undefined matrix state: assemble and factorise again, step by step
+        tasks_penalty.store(64, std::memory_order_relaxed);
+        if ((st = launch_assemble(gp, s)) != ALABI_OK) return st;
+        if ((st = launch_cholesky(gp, s)) != ALABI_OK) return st;
+        ALABI_HIP_CHECK(hipMemcpyAsync(&gp->host_status[0], gp->info, sizeof(int), hipMemcpyDeviceToHost, s));
+        ALABI_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    const int info = gp->host_status[0];
     gp->last_pivot = info;
     if (info != 0) return ALABI_NOT_POSITIVE_DEFINITE;
     gp->computed = true;

@@ -76,6 +76,7 @@ struct alabi_gp {
     int* flags = nullptr;     // [1] time-out flag of the dataflow solve
     double* red = nullptr;    // [4] reductions (logdet, r.alpha)
     int* info = nullptr;      // [1] Cholesky info (0 ok, else 1-based pivot)
+    int* host_status = nullptr;   // pinned [2]: read-back of (info, task-queue time-out) after a factorisation
     int* chol_ctl = nullptr;  // task-queue factorisation: [0] queue head, [1] time-out flag, [2 + i * nb + j] tile versions
     size_t chol_ctl_ints = 0;
     double* ws = nullptr;     // predict-variance workspace
@@ -158,11 +159,12 @@ struct alabi_ens {
 namespace alabi {
 // gp_assemble.hip
 int launch_prepare_inputs(alabi_gp* gp, const double* X, int N, hipStream_t s);
-int launch_assemble(alabi_gp* gp, hipStream_t s);
+int launch_assemble(alabi_gp* gp, hipStream_t s, int zero_ctl_ints = 0);   // also clears gp->info and the first zero_ctl_ints words of gp->chol_ctl
 int launch_kernel_matrix(const double* X1, int n1, const double* X2, int n2, int d, double amp,
                          const DimVec& inv_len, KernelFn kf, double* K, hipStream_t s);
 // gp_cholesky.hip
 int launch_cholesky(alabi_gp* gp, hipStream_t s);
+int cholesky_tasks_prepare(alabi_gp* gp, hipStream_t s, int* ctl_ints);   // > 0: the task queue will run, its control words (to be zeroed by the assembly)
 int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched);
 // gp_solve.hip
 int launch_alpha(alabi_gp* gp, hipStream_t s);

@@ -29,9 +29,13 @@ prepare_inputs_kernel(const double* __restrict__ X, int N, int Npad, int d, int 
 // 512-byte row segments), each thread owns 16 rows of one column.
 __global__ void __launch_bounds__(256)
 assemble_lower_kernel(const double* __restrict__ Xt, int N, int Npad, int d, double amp, double wn, KernelFn kf,
-                      double* __restrict__ K) {
+                      double* __restrict__ K, int* __restrict__ zero, int zero_ints, int* __restrict__ info) {
     __shared__ double xi[ALABI_MAX_DIM][64];
     __shared__ double xj[ALABI_MAX_DIM][64];
+    // the factorisation's control words (task-queue head, time-out flag, tile versions) and its status word start at zero:
+    // cleared here instead of by two memset nodes in front of the factorisation kernel
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < zero_ints; i += gridDim.x * 256) zero[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *info = 0;
     // linear tile id -> (bi >= bj)
     int t = blockIdx.x;
     int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -99,11 +103,11 @@ int launch_prepare_inputs(alabi_gp* gp, const double* X, int N, hipStream_t s) {
     return ALABI_OK;
 }
 
-int launch_assemble(alabi_gp* gp, hipStream_t s) {
+int launch_assemble(alabi_gp* gp, hipStream_t s, int zero_ctl_ints) {
     int nb = gp->Npad / 64;
     int tiles = nb * (nb + 1) / 2;
     hipLaunchKernelGGL(assemble_lower_kernel, dim3(tiles), dim3(256), 0, s, gp->Xt, gp->N, gp->Npad,
-                       gp->d, exp(gp->log_amp), exp(gp->log_wn), gp->kf, gp->L);
+                       gp->d, exp(gp->log_amp), exp(gp->log_wn), gp->kf, gp->L, gp->chol_ctl, zero_ctl_ints, gp->info);
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

@@ -17,8 +17,10 @@
 //                     pivot is reported as LAPACK's potrf `info` (1-based).
 // The matrix is [Npad, Npad] row-major with identity padding, so every block is full.
 #include <cstdlib>
+#include <array>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 #include "gp_device.hpp"
 
@@ -515,7 +517,11 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
 // Order per block column k: CHAIN(k+1) first, then the panel solves, then the updates of column k+1 (the next chain's
 // inputs), then the rest -- the chain never queues behind bulk updates.  ver[i][j] = number of steps applied to tile (i, j);
 // j + 1 means final.
+// type & 255: 0 CHAIN(k), 1 TRSM(i,k), 2 UPDATE(i,j,k..k+cnt-1) with cnt = type >> 8 consecutive block columns (chol_build_tasks)
 struct CholTask { int type, i, j, k; };
+#define ALABI_CHOL_TASKS_MAX_NB 160   // default upper end of the one-launch task queue (N <= 10240); beyond: panels of 8 block columns
+#define ALABI_CHOL_PLAIN_MIN 4   // block columns per UPDATE from which its operands are read with ordinary loads behind one acquire
+
 
 __device__ inline void tile_load_sc1(double (*T)[66], const double* __restrict__ src, int ld, int tid) {
 #pragma unroll
@@ -562,6 +568,7 @@ __device__ inline void trsm_tile_lds(double (*lkk)[66], double (*bs)[66], const 
 __shared__ double ct_T0[64][66];
 __shared__ double ct_T1[64][66];
 __shared__ double ct_T2[64][66];                                      // CHAIN: the diagonal tile, parked while the panel tile is solved
+__shared__ double ct_T3[64][66];                                      // UPDATE over several block columns: second operand pair (T2, T3)
 __shared__ double ct_di[64];
 // One 16-column slab of the panel solve (CHAIN: the slabs of L[k-1,k-1] arrive one by one, see ct_potrf_publish).
 // The slab's recurrence for all 64 rows of the tile by ONE wave (lane = row; the instruction stream is the same as for 16
@@ -649,14 +656,36 @@ __device__ inline void tile_put(double (*T)[66], const TileRegs& r, int tid) {
     }
 }
 
+// The same through 16-byte write-through-coherent (sc1) buffer loads: half the load instructions and twice the bytes per request
+// (8-byte sc1 accesses run at 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md) -- the operand stream of the bulk updates.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct TileRegs16 { u32x4 v[8]; };
+// PLAIN: ordinary (L2-cached) loads -- valid behind an agent-scope acquire of the hand-off that published the tile (Guideline 16)
+template <bool PLAIN>
+__device__ inline void tile_fetch16(TileRegs16& r, __amdgpu_buffer_rsrc_t rs, unsigned tile_bytes, int ld, int tid) {
+#pragma unroll
+    for (int e_ = 0; e_ < 8; ++e_) {
+        const int e = tid + 256 * e_;
+        r.v[e_] = __builtin_amdgcn_raw_buffer_load_b128(rs, tile_bytes + (unsigned)(((e >> 5) * ld + 2 * (e & 31)) * 8), 0, PLAIN ? 0 : 16);
+    }
+}
+__device__ inline void tile_put16(double (*T)[66], const TileRegs16& r, int tid) {
+#pragma unroll
+    for (int e_ = 0; e_ < 8; ++e_) {
+        const int e = tid + 256 * e_;
+        *reinterpret_cast<u32x4*>(&T[e >> 5][2 * (e & 31)]) = r.v[e_];
+    }
+}
+
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __restrict__ tasks, int ntasks, int* __restrict__ ctl,
                   int* __restrict__ info, double* __restrict__ dinv, int spin_limit) {
-    double (*T0)[66] = ct_T0; double (*T1)[66] = ct_T1; double (*T2)[66] = ct_T2; double* di = ct_di;
-    __shared__ int task_s[5];
+    double (*T0)[66] = ct_T0; double (*T1)[66] = ct_T1; double (*T2)[66] = ct_T2; double (*T3)[66] = ct_T3; double* di = ct_di;
+    __shared__ int task_s[6];
     int* head = ctl; int* err = ctl + 1; int* ver = ctl + 2;          // ver[i * nb + j]
     int* sver = ctl + 2 + nb * nb;                                    // sver[k]: slabs of L[k,k] published so far (0..4)
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(A, 0, (unsigned)ld * (unsigned)ld * 8u, 0x00020000);
     // Panel solve of the tile in T1 against L[kk,kk], consumed slab by slab as its factorisation publishes them (sver[kk] =
     // slabs written through so far): wait (bounded), fetch the slab's 64 x 16 block and its reciprocals, solve the slab,
     // update the later slabs on the matrix cores.  false = a wait ran out (err is set; every thread returns).
@@ -748,11 +777,12 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
         if (tid == 0) {
             const int idx = atomicAdd(head, 1);
             task_s[4] = idx;
-            if (idx < ntasks) { const CholTask t = tasks[idx]; task_s[0] = t.type; task_s[1] = t.i; task_s[2] = t.j; task_s[3] = t.k; }
+            if (idx < ntasks) { const CholTask t = tasks[idx]; task_s[0] = t.type & 255; task_s[1] = t.i; task_s[2] = t.j; task_s[3] = t.k; task_s[5] = t.type >> 8; }
         }
         __syncthreads();
         if (task_s[4] >= ntasks) return;
         const int type = task_s[0], ti = task_s[1], tj = task_s[2], tk = task_s[3];
+        const int tcnt = task_s[5] > 0 ? task_s[5] : 1;                 // UPDATE: block columns tk .. tk + tcnt - 1
 #ifdef ALABI_CHOL_PROF
         const long long pw0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -767,9 +797,10 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
                 if (tk == 0) { di_ = 0; dj_ = 0; }
             } else if (type == 1) {                                   // TRSM(i,k): tile (i,k) at k (L[k,k] is taken slab by slab)
                 if (l == 1) { di_ = ti; dj_ = tk; need = tk; }
-            } else {                                                  // UPDATE(i,j,k): (i,k), (j,k) final, tile (i,j) at k
-                if (l == 0) { di_ = ti; dj_ = tk; need = tk + 1; }
-                if (l == 1) { di_ = tj; dj_ = tk; need = tk + 1; }
+            } else {                                                  // UPDATE(i,j,k..kl): (i,kl), (j,kl) final (then so are the
+                const int kl = tk + tcnt - 1;                         // panels before them), tile (i,j) at version k
+                if (l == 0) { di_ = ti; dj_ = kl; need = kl + 1; }
+                if (l == 1) { di_ = tj; dj_ = kl; need = kl + 1; }
                 if (l == 2) { di_ = ti; dj_ = tj; need = tk; }
             }
             const bool active = l < 3 && need > 0;
@@ -785,6 +816,13 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
                 __builtin_amdgcn_s_sleep(2);
             }
             if (!ok && l == 0) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); task_s[4] = ntasks; }
+            // an UPDATE over a whole group of block columns streams its operand tiles with ordinary loads (they can hit in the XCD's
+            // L2, where the neighbouring tasks of the same tile column have just put them; write-through-coherent loads always go
+            // out to the fabric, and the bulk updates are bound by exactly that traffic): one acquire per task makes that valid
+            if (type == 2 && tcnt >= ALABI_CHOL_PLAIN_MIN) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         __syncthreads();
 #ifdef ALABI_CHOL_PROF
@@ -792,34 +830,78 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
 #endif
         if (task_s[4] >= ntasks) return;                              // a wait ran out: every workgroup leaves at its next check
         if (type == 2) {
-            // ---------------- UPDATE(i, j, k)
-            TileRegs ra, rb;
-            tile_fetch(ra, A + (size_t)(ti * 64) * ld + tk * 64, ld, tid);
-            tile_fetch(rb, A + (size_t)(tj * 64) * ld + tk * 64, ld, tid);
-            double* C = A + (size_t)(ti * 64 + 16 * w) * ld + tj * 64;
-            v4f64 acc[4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[n][i] = __longlong_as_double((long long)__hip_atomic_load(
-                        reinterpret_cast<const unsigned long long*>(C + (size_t)(lk + 4 * i) * ld + 16 * n + lr), __ATOMIC_RELAXED,
-                        __HIP_MEMORY_SCOPE_AGENT));
-            tile_put(T0, ra, tid); tile_put(T1, rb, tid);
-            __syncthreads();
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const double a = -T0[16 * w + lr][4 * ks + lk];
-#pragma unroll
-                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T1[16 * n + lr][4 * ks + lk], acc[n], 0, 0, 0);
+            // ---------------- UPDATE(i, j, k .. k + tcnt - 1): C(i,j) -= sum_k' A(i,k') A(j,k')^T, accumulated in registers over
+            // the whole range (C is read and written ONCE per task); the operand tiles of column k' + 1 are in flight while the
+            // matrix cores work on column k' (two LDS operand pairs).  Measured and not kept: operands two columns ahead (a
+            // second register set; as part of this kernel it spills, as a function of its own the call costs every task more than
+            // the deeper prefetch gains -- the grouped tasks were no faster, so the fetch latency is not what bounds them).
+#ifdef ALABI_CHOL_PROF
+            const long long u0 = __builtin_amdgcn_s_memrealtime();
+            long long u1 = u0, u2 = u0;
+#endif
+            auto update_range = [&](auto plain_tag) {
+                constexpr bool PL = decltype(plain_tag)::value;
+                TileRegs16 ra, rb;
+                const unsigned row_i = (unsigned)(ti * 64) * (unsigned)ld * 8u, row_j = (unsigned)(tj * 64) * (unsigned)ld * 8u;
+                tile_fetch16<PL>(ra, arsrc, row_i + (unsigned)tk * 512u, ld, tid);
+                tile_fetch16<PL>(rb, arsrc, row_j + (unsigned)tk * 512u, ld, tid);
+                double* C = A + (size_t)(ti * 64 + 16 * w) * ld + tj * 64;
+                v4f64 acc[4];
+    #pragma unroll
+                for (int n = 0; n < 4; ++n)
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[n][i] = __longlong_as_double((long long)__hip_atomic_load(
+                            reinterpret_cast<const unsigned long long*>(C + (size_t)(lk + 4 * i) * ld + 16 * n + lr), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT));
+                tile_put16(T0, ra, tid); tile_put16(T1, rb, tid);
+                // every load so far has landed before the loop starts: otherwise the compiler's wait for the C tile sits INSIDE the loop
+                // (vmcnt is one in-order counter) and drains the operand prefetch of every iteration
+                __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+                __syncthreads();
+#ifdef ALABI_CHOL_PROF
+                u1 = __builtin_amdgcn_s_memrealtime();
+#endif
+                for (int c = 0; c < tcnt; ++c) {
+                    const bool more = c + 1 < tcnt;
+                    if (more) {
+                        tile_fetch16<PL>(ra, arsrc, row_i + (unsigned)(tk + c + 1) * 512u, ld, tid);
+                        tile_fetch16<PL>(rb, arsrc, row_j + (unsigned)(tk + c + 1) * 512u, ld, tid);
+                    }
+                    double (*Ta)[66] = (c & 1) ? T2 : T0;
+                    double (*Tb)[66] = (c & 1) ? T3 : T1;
+    #pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) {
+                        const double a = -Ta[16 * w + lr][4 * ks + lk];
+    #pragma unroll
+                        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Tb[16 * n + lr][4 * ks + lk], acc[n], 0, 0, 0);
+                    }
+                    if (more) {                                           // the other pair was last read one iteration ago: every wave is past that barrier
+                        tile_put16((c & 1) ? T0 : T2, ra, tid); tile_put16((c & 1) ? T1 : T3, rb, tid);
+                        __syncthreads();
+                    }
+                }
+    #pragma unroll
+                for (int n = 0; n < 4; ++n)
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(C + (size_t)(lk + 4 * i) * ld + 16 * n + lr),
+                                           (unsigned long long)__double_as_longlong(acc[n][i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            if (tcnt >= ALABI_CHOL_PLAIN_MIN) update_range(std::true_type{}); else update_range(std::false_type{});
+#ifdef ALABI_CHOL_PROF
+            u2 = __builtin_amdgcn_s_memrealtime();
+#endif
+            publish_version(ver + ti * nb + tj, tk + tcnt, tid);
+#ifdef ALABI_CHOL_PROF
+            if (tid == 0) {   // 10-ns units, grouped updates [8..13], single-column updates [16..21]: wait for deps, first fetch + C, loop, store + publish, count, columns
+                unsigned long long* up = reinterpret_cast<unsigned long long*>(ctl + ((2 + nb * nb + nb + 1) & ~1)) + (tcnt >= ALABI_CHOL_PLAIN_MIN ? 8 : 16);
+                const long long u3 = __builtin_amdgcn_s_memrealtime();
+                atomicAdd(up + 0, (unsigned long long)(u0 - pw0)); atomicAdd(up + 1, (unsigned long long)(u1 - u0));
+                atomicAdd(up + 2, (unsigned long long)(u2 - u1)); atomicAdd(up + 3, (unsigned long long)(u3 - u2));
+                atomicAdd(up + 4, 1ull); atomicAdd(up + 5, (unsigned long long)tcnt);
             }
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(C + (size_t)(lk + 4 * i) * ld + 16 * n + lr),
-                                       (unsigned long long)__double_as_longlong(acc[n][i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            publish_version(ver + ti * nb + tj, tk + 1, tid);
+#endif
         } else if (type == 1) {
             // ---------------- TRSM(i, k)
             {
@@ -930,26 +1012,76 @@ static int tiles_in_cols(int ntr, int tc0, int tc1) {
     return n;
 }
 
-// Task list of the queue kernel for nb block columns (built once per nb and kept on the device).
+// Task list of the queue kernel for nb block columns: a static topological order, drawn from one counter.
+//   step k (block column k is final once its tasks are done):
+//     CHAIN(k+1)                      solve tile (k+1,k), update and factorise tile (k+1,k+1), all in one workgroup
+//     TRSM(i,k), i >= k+2             the rest of panel k
+//     UPDATE(i,j,k) with ONE block column for the tile columns j = k+1 (inputs of CHAIN(k+2) and of panel k+1) .. k+near
+//     UPDATE(i,j,[far(j), k]) for tile column j = k+1+near: everything it has not received yet, in one task
+//     UPDATE(i,j,[k+1-gk, k]) for the tile columns beyond, whenever a group of gk block columns is complete
+//   far(j) = gk * floor((j - near) / gk) (0 below).  A tile far from the chain takes the block columns in groups of gk -- C is
+//   read and written once per group instead of once per block column, and a task carries gk x 64 matrix-core instructions per wave
+//   against its fixed cost (queue draw, dependency poll, first fetch, C round trip: 3.5 us against 2.7 us per block column) --,
+//   catches up in one task when the chain is near + 1 columns away, and from then on takes every block column as soon as it is
+//   final, so that nothing the chain needs waits for a group to fill.
+// Every task depends only on tasks before it in the list (tests/test_abi.py replays the order on the host).
+static void chol_build_tasks(int nb, int gk, int near, std::vector<CholTask>& t) {
+    auto far = [&](int j) { return (j - near) < 0 ? 0 : (j - near) / gk * gk; };
+    t.clear();
+    t.push_back({0, 0, 0, 0});
+    for (int k = 0; k + 1 < nb; ++k) {
+        t.push_back({0, k + 1, k + 1, k + 1});
+        for (int i = k + 2; i < nb; ++i) t.push_back({1, i, k, k});
+        for (int i = k + 2; i < nb; ++i) t.push_back({2 | (1 << 8), i, k + 1, k});
+        for (int j = k + 2; j < nb && j <= k + near; ++j)
+            for (int i = j; i < nb; ++i) t.push_back({2 | (1 << 8), i, j, k});
+        const int jc = k + 1 + near;                          // catches up: block columns [far(jc), k]
+        if (jc < nb && far(jc) <= k)
+            for (int i = jc; i < nb; ++i) t.push_back({2 | ((k + 1 - far(jc)) << 8), i, jc, far(jc)});
+        if ((k + 1) % gk == 0)
+            for (int j = k + 1 + near; j < nb; ++j) {
+                if (far(j) < k + 1) continue;                 // (j = k+1+near has far(j) = k+1 here: its catch-up task above is empty)
+                for (int i = j; i < nb; ++i) t.push_back({2 | (gk << 8), i, j, k + 1 - gk});
+            }
+    }
+}
+
+// Block columns per far update and width of the near band, by size: measured in tools/prof_cholesky.py
+static void chol_task_shape(int nb, int* gk, int* near) {
+    // measured (profiles/r03_cholesky_task_shapes.txt): N = 2000: (4,4) 0.585 ms, (8,4) 0.578, (16,3) 0.627; N = 3072: (4,2) 0.98,
+    // (16,3) 0.96; N = 5000: (4,2) 2.18, (8,4) 2.06, (16,4) 1.98; N = 8192: (16,3) 5.87, (32,3) 6.19; N = 10000: (8,2) 10.3, (16,3) 9.91
+    *gk = nb < 40 ? 4 : nb < 64 ? 8 : 16; *near = nb < 100 ? 4 : 3;
+    if (const char* e = getenv("ALABI_CHOL_GK")) { const int v = atoi(e); if (v >= 1 && v <= 64) *gk = v; }
+    if (const char* e = getenv("ALABI_CHOL_NEAR")) { const int v = atoi(e); if (v >= 1 && v <= 16) *near = v; }
+}
+
+extern "C" int alabi_debug_chol_tasks(int nb, int* out, int cap) {   // host only: the list as (type, i, j, k) quadruples; returns the count
+    int gk, near;
+    chol_task_shape(nb, &gk, &near);
+    std::vector<CholTask> t;
+    chol_build_tasks(nb, gk, near, t);
+    if (out)
+        for (size_t q = 0; q < t.size() && (int)q < cap; ++q) { out[4 * q] = t[q].type; out[4 * q + 1] = t[q].i; out[4 * q + 2] = t[q].j; out[4 * q + 3] = t[q].k; }
+    return (int)t.size();
+}
+
+// The list on the device, built once per (device, nb, shape) and kept.
 static int chol_task_list(int nb, const CholTask** dev, int* count) {
     static std::mutex mu;
-    static std::map<int, std::pair<CholTask*, int>> cache;
+    static std::map<std::array<int, 4>, std::pair<CholTask*, int>> cache;
+    int device = 0, gk, near;
+    ALABI_HIP_CHECK(hipGetDevice(&device));
+    chol_task_shape(nb, &gk, &near);
     std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(nb);
+    const std::array<int, 4> key{device, nb, gk, near};
+    auto it = cache.find(key);
     if (it == cache.end()) {
         std::vector<CholTask> t;
-        t.push_back({0, 0, 0, 0});
-        for (int k = 0; k + 1 < nb; ++k) {
-            t.push_back({0, k + 1, k + 1, k + 1});                                   // CHAIN(k+1): needs only CHAIN(k) and older updates
-            for (int i = k + 2; i < nb; ++i) t.push_back({1, i, k, k});               // the rest of panel k
-            for (int i = k + 2; i < nb; ++i) t.push_back({2, i, k + 1, k});           // column k+1 first: inputs of CHAIN(k+2) / panel k+1
-            for (int j = k + 2; j < nb; ++j)
-                for (int i = j; i < nb; ++i) t.push_back({2, i, j, k});
-        }
+        chol_build_tasks(nb, gk, near, t);
         CholTask* d = nullptr;
         ALABI_HIP_CHECK(hipMalloc(&d, t.size() * sizeof(CholTask)));
         ALABI_HIP_CHECK(hipMemcpy(d, t.data(), t.size() * sizeof(CholTask), hipMemcpyHostToDevice));
-        it = cache.emplace(nb, std::make_pair(d, (int)t.size())).first;
+        it = cache.emplace(key, std::make_pair(d, (int)t.size())).first;
     }
     *dev = it->second.first; *count = it->second.second;
     return ALABI_OK;
@@ -957,29 +1089,39 @@ static int chol_task_list(int nb, const CholTask** dev, int* count) {
 
 // 1 when the queue kernel was launched (the caller reads gp->chol_ctl[1] after its synchronisation: non-zero = a wait ran out,
 // the matrix is in an undefined state and must be assembled and factorised again on the launch-per-step path).
-int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
-    *launched = 0;
-    const int ld = gp->Npad, nb = gp->Npad / 64;
-    // Default for 16..84 block columns (N = 961..5376; ALABI_CHOL_TASKS=0 / 1 forces it off / on for 3..128).  Measured
-    // (tools/prof_cholesky.py, assembly included): N = 1024 0.34 vs 0.46 ms launch-per-step, 2000 0.60-0.64 vs 0.93, 3072 1.03
-    // vs 1.38, 4096 1.7 vs 2.06, 5000 2.71 vs 2.91, 6000 4.08 vs 4.00 (from there on the 64 x 64 rank-64 updates of the bulk
-    // dominate and the launch-per-step kernels, then the panel path, are ahead); below 1024 the two are equal.
+// Will the task queue factorise this matrix?  If so its control words exist and *ctl_ints says how many the assembly kernel
+// has to clear (queue head, time-out flag, tile versions, slab counters).
+int cholesky_tasks_prepare(alabi_gp* gp, hipStream_t s, int* ctl_ints_out) {
+    *ctl_ints_out = 0;
+    const int nb = gp->Npad / 64;
+    // Default for 16..160 block columns (N = 961..10240; ALABI_CHOL_TASKS=0 / 1 forces it off / on for 3..256).  Measured
+    // (tools/prof_chol_tasks.py, assembly included; round 3, updates over groups of block columns): N = 1024 0.33 ms (0.46 launch
+    // per step), 2000 0.59 (0.89), 3072 0.96 (1.39), 4096 1.40 (2.05), 5000 2.0 (2.9), 6000 2.86 (3.96), 8192 5.9 (6.9),
+    // 10000 9.9 (10.8 panels of 8), 12000 15.9 (15.4), 16000 35.1 (30.5): from 11000 on the rank-512 panel path is ahead.
     const char* env = getenv("ALABI_CHOL_TASKS");
     const bool forced_on = env && env[0] == '1', forced_off = env && env[0] == '0';
-    if (nb < 3 || nb > 128 || forced_off || (!forced_on && (nb < 16 || nb > 84))) return ALABI_OK;
-    const size_t ctl_ints = 2 + (size_t)nb * nb + nb + 66;             // + 66: alignment + phase timers of an ALABI_CHOL_PROF build
+    if (nb < 3 || nb > 256 || forced_off || (!forced_on && (nb < 16 || nb > ALABI_CHOL_TASKS_MAX_NB))) return ALABI_OK;
+    const size_t ctl_ints = 2 + (size_t)nb * nb + nb + 130;            // + 130: alignment + phase timers of an ALABI_CHOL_PROF build
     if (gp->chol_ctl_ints < ctl_ints) {
         if (gp->chol_ctl) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); ALABI_HIP_CHECK(hipFree(gp->chol_ctl)); gp->chol_ctl = nullptr; }
-        const size_t cap_nb = gp->n_cap / 64 < 128 ? gp->n_cap / 64 : 128;
-        const size_t cap = 2 + 66 + cap_nb * cap_nb + cap_nb;
+        const size_t cap_nb = gp->n_cap / 64 < 256 ? gp->n_cap / 64 : 256;
+        const size_t cap = 2 + 130 + cap_nb * cap_nb + cap_nb;
         ALABI_HIP_CHECK(hipMalloc(&gp->chol_ctl, (cap > ctl_ints ? cap : ctl_ints) * sizeof(int)));
         gp->chol_ctl_ints = cap > ctl_ints ? cap : ctl_ints;
     }
+    *ctl_ints_out = (int)ctl_ints;
+    return ALABI_OK;
+}
+
+// 1 when the queue kernel was launched (the caller reads gp->chol_ctl[1] after its synchronisation: non-zero = a wait ran out,
+// the matrix is in an undefined state and must be assembled and factorised again on the launch-per-step path).  The control
+// words and gp->info were cleared by launch_assemble(gp, s, ctl_ints).
+int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
+    *launched = 0;
+    const int ld = gp->Npad, nb = gp->Npad / 64;
     const CholTask* tasks = nullptr;
     int ntasks = 0, st;
     if ((st = chol_task_list(nb, &tasks, &ntasks)) != ALABI_OK) return st;
-    ALABI_HIP_CHECK(hipMemsetAsync(gp->chol_ctl, 0, ctl_ints * sizeof(int), s));
-    ALABI_HIP_CHECK(hipMemsetAsync(gp->info, 0, sizeof(int), s));
     int dev = 0, n_cu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -990,9 +1132,14 @@ int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
     ALABI_LAUNCH_CHECK();
 #ifdef ALABI_CHOL_PROF
     {
-        long long h[8];
+        long long h[24];
         (void)hipMemcpyAsync(h, gp->chol_ctl + ((2 + nb * nb + nb + 1) & ~1), sizeof(h), hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
+        for (int q = 8; q <= 16; q += 8)
+            if (h[q + 4] > 0)
+                fprintf(stderr, "[chol_tasks_kernel] per %s UPDATE (us): wait for deps %.2f, first fetch + C %.2f, loop %.2f (%.2f per block column), C store + publish %.2f (n=%lld, %.2f columns each)\n",
+                        q == 8 ? "grouped" : "single-column", 0.01 * h[q] / h[q + 4], 0.01 * h[q + 1] / h[q + 4], 0.01 * h[q + 2] / h[q + 4],
+                        0.01 * h[q + 2] / (h[q + 5] ? h[q + 5] : 1), 0.01 * h[q + 3] / h[q + 4], h[q + 4], (double)h[q + 5] / h[q + 4]);
         if (h[6] > 0)
             fprintf(stderr, "[chol_tasks_kernel] per CHAIN (us): wait %.2f loads %.2f trsm %.2f store+publish %.2f mfma %.2f potrf %.2f store+publish %.2f (n=%lld)\n",
                     0.01 * h[7] / h[6], 0.01 * h[0] / h[6], 0.01 * h[1] / h[6], 0.01 * h[2] / h[6], 0.01 * h[3] / h[6], 0.01 * h[4] / h[6],
@@ -1005,7 +1152,7 @@ int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
 
 int launch_cholesky(alabi_gp* gp, hipStream_t s) {
     const int ld = gp->Npad, nb = gp->Npad / 64;
-    ALABI_HIP_CHECK(hipMemsetAsync(gp->info, 0, sizeof(int), s));
+    // (gp->info was cleared by the assembly kernel, which always runs just before)
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, s, gp->L, ld, 0, gp->info, gp->dinv);
     // Block columns per panel (0: rank-64 updates of the whole trailing matrix).  Measured on MI355X (tools/prof_cholesky.py):
     // the panel path wins from about N = 8000 on (N = 10000: 14.3 -> 11.3 ms, N = 16000: 49.6 -> 31.4 ms with panels of 8;

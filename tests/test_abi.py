@@ -51,3 +51,45 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+@pytest.mark.parametrize("gk,near", [(4, 2), (1, 1), (8, 3), (2, 1), (3, 5)])
+def test_cholesky_task_list_is_a_topological_order(gk, near, monkeypatch):
+    """The static task list of the one-launch Cholesky (alabi/core.py:1158 -> gp.compute): replayed in order on the host,
+    every task finds its inputs produced by EARLIER tasks (a workgroup only ever waits for lower-numbered tasks: no deadlock),
+    every tile receives every block column exactly once and in order, and every panel tile is solved exactly once."""
+    from alabi_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.alabi_debug_chol_tasks.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    monkeypatch.setenv("ALABI_CHOL_GK", str(gk))
+    monkeypatch.setenv("ALABI_CHOL_NEAR", str(near))
+    for nb in (3, 5, 16, 33, 79):
+        n = lib.alabi_debug_chol_tasks(nb, None, 0)
+        buf = (ctypes.c_int * (4 * n))()
+        assert lib.alabi_debug_chol_tasks(nb, buf, n) == n
+        ver = [[0] * nb for _ in range(nb)]                  # block columns applied to tile (i, j)
+        final = [[False] * nb for _ in range(nb)]            # tile (i, j) holds its block of L
+        for q in range(n):
+            ty, i, j, k = buf[4 * q] & 255, buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]
+            cnt = buf[4 * q] >> 8
+            if ty == 0:                                      # CHAIN(k): solve (k, k-1), update + factorise (k, k)
+                assert i == j == k and not final[k][k]
+                if k > 0:
+                    assert final[k - 1][k - 1] and ver[k][k - 1] == k - 1 and not final[k][k - 1]
+                    assert ver[k][k] == k - 1
+                    final[k][k - 1] = True
+                    ver[k][k] = k
+                final[k][k] = True
+            elif ty == 1:                                    # TRSM(i, k)
+                assert j == k and i >= k + 2 and final[k][k] and ver[i][k] == k and not final[i][k]
+                final[i][k] = True
+            else:                                            # UPDATE(i, j, k .. k + cnt - 1)
+                assert ty == 2 and cnt >= 1 and i >= j > k + cnt - 1
+                assert not (i == j == k + cnt)               # the last column of a diagonal tile belongs to CHAIN
+                assert ver[i][j] == k and final[i][k + cnt - 1] and final[j][k + cnt - 1]
+                ver[i][j] = k + cnt
+        for i in range(nb):
+            for j in range(i + 1):
+                assert final[i][j] and ver[i][j] == j, (nb, i, j)
