@@ -747,6 +747,23 @@ int alabi_ens_half_step(alabi_ens* e, double* coords, double* logp, int t, int s
     return launch_ens_half_args(e, h, part_end - part_begin, as_stream(stream));
 }
 
+}  // extern "C" (reopened below)
+namespace alabi {
+int ens_sync_consts(alabi_ens* e, hipStream_t s) { return sync_consts(e, s); }
+int alabi_ens_half_step_hist(alabi_ens* e, const double* coords, const double* logp, int t, int split, int part_begin, int part_end,
+                             const double* shist, double* out, hipStream_t s) {
+    if (!e || t < 0 || t >= e->drawn_n || e->E != 1 || !shist || !out) return ALABI_BAD_ARGUMENT;
+    int st = sync_consts(e, s);
+    if (st != ALABI_OK) return st;
+    HalfArgs h = base_args(e, const_cast<double*>(coords), const_cast<double*>(logp));
+    h.rec = offset_draws(e->draws, (size_t)t * e->W);
+    h.local_t = t; h.split = split; h.part_begin = part_begin;
+    h.shist = shist; h.sout = out;
+    return launch_ens_half_args(e, h, part_end - part_begin, s);
+}
+}  // namespace alabi
+extern "C" {
+
 int alabi_ens_propose(alabi_ens* e, const double* coords, int t, int split, int gate_box, double* q, double* like,
                       void* stream) {
     if (!e || !coords || !q || t < 0 || t >= e->drawn_n || (split != 0 && split != 1) || e->E != 1) return ALABI_BAD_ARGUMENT;

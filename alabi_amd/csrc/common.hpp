@@ -214,6 +214,11 @@ struct HalfArgs {
     double prior_const;
     double amp, mean;
     KernelFn kf;
+    // sharded ensemble (ens_sharded.hip): the walker rows live in a history indexed by (half step, rank, slot); rec.link[2 pos] holds
+    // the word offsets (own | partner << 32, -1 = the state in coords / logp) of the two rows a proposal reads, the result row
+    // (coords, logp, accepted) of proposal blockIdx.x goes to sout + blockIdx.x (d + 2) and coords / logp are left alone
+    const double* shist = nullptr;
+    double* sout = nullptr;
 };
 int launch_ens_draw(alabi_ens* e, int nsteps, double a, hipStream_t s);
 int launch_ens_prep(alabi_ens* e, const int* order, int n0, const double* u_z, const int* partner,
@@ -223,6 +228,11 @@ int launch_ens_lnprob(alabi_ens* e, const double* coords, int nwalkers, double* 
 int launch_ens_propose(alabi_ens* e, const HalfArgs& args, int nblocks, int gate_box, double* q, double* like, hipStream_t s);
 int launch_ens_accept(alabi_ens* e, const HalfArgs& args, int count, const double* q, const double* lp_new, hipStream_t s);
 int launch_ens_advance(alabi_ens* e, long long n, hipStream_t s);
+// half step of drawn local step t on list slice [begin, end) of `split` in history mode (ens_sharded.hip): rows read from shist / the
+// start state, new rows written to `out` (one row of d + 2 doubles per proposal); coords / logp are not modified
+int ens_sync_consts(alabi_ens* e, hipStream_t s);   // (inv_len, bounds, prior) on the device match the GP's hyper-parameters
+int alabi_ens_half_step_hist(alabi_ens* e, const double* coords, const double* logp, int t, int split, int part_begin, int part_end,
+                             const double* shist, double* out, hipStream_t s);
 bool ens_stream_fits(const alabi_ens* e);
 int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
                       long long* n_accept, hipStream_t s);

@@ -2,12 +2,22 @@
 //
 // The reference spreads emcee's per-walker lnprob calls over a process pool (alabi/core.py:2300, :2322).  Here the active
 // half of every half step is partitioned over the ranks (one process per GPU); each rank runs the half-step kernel on its
-// slice [begin, end) of that half's list, then the updated (coords, logp) rows are exchanged with ONE all-gather per half
-// step, enqueued on the run stream -- no host read-back between half steps.  The draws are counter-based (seed, step,
-// walker id), so every rank builds identical lists without communication and the chain does not depend on the number of
-// ranks.  The collective is RCCL (ncclAllGather over xGMI), resolved with dlopen at run time so that libalabi_hip.so has
-// no link-time dependency on it; a communicator can also carry a caller-supplied host function (test rig: two ranks on
-// one GPU, which RCCL refuses).
+// slice [begin, end) of that half's list, then the new rows are exchanged with ONE all-gather per half step, enqueued on
+// the run stream -- no host read-back between half steps.  The draws are counter-based (seed, step, walker id), so every
+// rank builds identical lists without communication and the chain does not depend on the number of ranks.
+//
+// Two enqueues per half step, nothing else: the walker rows live in a HISTORY indexed by (half step, rank, slot) -- the
+// half-step kernel writes its slice's new rows (coords, logp, accepted) straight into its own segment of the half step's
+// block, the all-gather runs IN PLACE on that block (send = the rank's segment of recv), and the next kernels read the two
+// rows of a proposal from wherever the draws say they were produced (shard_link_kernel: position of a walker in the step
+// that produced its current row -> rank and slot).  There is no pack kernel, no unpack kernel and no per-step chain kernel:
+// the chain, the acceptance counters and the final state are gathered from the history once per chunk
+// (shard_chain_kernel).  With RCCL (or no communicator traffic at all: one rank) the enqueues of a chunk are captured in a
+// hipGraph and replayed.
+//
+// The collective is RCCL (ncclAllGather over xGMI), resolved with dlopen at run time so that libalabi_hip.so has no
+// link-time dependency on it; a communicator can also carry a caller-supplied host function (test rig: two ranks on one
+// GPU, which RCCL refuses).  UNMEASURED on multi-GPU hardware: one-rank RCCL rehearsal and gloo rigs only.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -21,10 +31,10 @@ struct alabi_comm {
     ncclComm_t nccl = nullptr;
     alabi_allgather_fn fn = nullptr;      // test rig
     void* user = nullptr;
-    double *send = nullptr, *recv = nullptr;          // [per * (d+1)], [nranks * per * (d+1)]
-    size_t send_cap = 0, recv_cap = 0;
-    long long *nacc_local = nullptr, *nacc_all = nullptr;   // [W], [nranks * W]
-    size_t nacc_cap = 0;
+    double* shist = nullptr;              // [2 chunk][nranks * per][d + 2] rows by (half step, rank, slot)
+    size_t shist_cap = 0;
+    hipGraphExec_t graph = nullptr;       // the enqueues of one chunk
+    struct Key { void *ens, *coords, *logp; int K; double a; long long gp_gen; } key{};
 };
 
 namespace alabi {
@@ -70,53 +80,65 @@ inline void slice_bounds(int n, int world, int rank, int* b, int* e) {
 }
 }  // namespace
 
-// rows of this rank's slice [begin, end) of the half's list -> send[(i - begin)][0..d] = (coords, logp)
-__global__ void __launch_bounds__(256)
-shard_pack_kernel(const int* __restrict__ order, int begin, int end, int d, const double* __restrict__ coords,
-                  const double* __restrict__ logp, double* __restrict__ send) {
-    const int i = blockIdx.x * 256 + threadIdx.x, row = d + 1;
-    if (i >= (end - begin) * row) return;
-    const int r = i / row, k = i % row, w = order[begin + r];
-    send[i] = (k < d) ? coords[(size_t)w * d + k] : logp[w];
-}
-
-// rows of every OTHER rank's slice out of recv[rank][per][d+1] into coords / logp
-__global__ void __launch_bounds__(256)
-shard_unpack_kernel(const int* __restrict__ order, int nS, int nranks, int me, int per, int d, const double* __restrict__ recv,
-                    double* __restrict__ coords, double* __restrict__ logp) {
-    const int i = blockIdx.x * 256 + threadIdx.x, row = d + 1;
-    if (i >= nS * row) return;
-    const int pos = i / row, k = i % row;
+// list position ph of a half of nS walkers -> slot of the (rank, slot) layout: shares differ by at most one, larger first
+__device__ inline int shard_slot(int ph, int nS, int nranks, int per) {
     const int base = nS / nranks, rem = nS % nranks;
-    // owner of list position pos (shares differ by at most one, larger shares first)
-    int r = (pos < rem * (base + 1)) ? pos / (base + 1) : rem + (base > 0 ? (pos - rem * (base + 1)) / base : 0);
-    if (r == me) return;
-    const int b = r * base + (r < rem ? r : rem);
-    const double v = recv[((size_t)r * per + (pos - b)) * row + k];
-    const int w = order[pos];
-    if (k < d) coords[(size_t)w * d + k] = v; else logp[w] = v;
+    const int r = (ph < rem * (base + 1)) ? ph / (base + 1) : rem + (base > 0 ? (ph - rem * (base + 1)) / base : 0);
+    return r * per + (ph - (r * base + (r < rem ? r : rem)));
 }
 
+// link[2 pos] = word offsets into the history of the two rows the proposal at list position pos reads (own | partner << 32;
+// -1: the row is the state the chunk started from).  Version v of walker x was produced by the proposal x made in step v - 1.
 __global__ void __launch_bounds__(256)
-shard_store_kernel(const double* __restrict__ coords, const double* __restrict__ logp, int W, int d, double* __restrict__ chain_row,
-                   double* __restrict__ lp_row) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (chain_row && i < W * d) chain_row[i] = coords[i];
-    if (lp_row && i < W) lp_row[i] = logp[i];
+shard_link_kernel(DrawBuffers b, int W, int n0, int nranks, int per, int row) {
+    const int t = blockIdx.x;
+    const size_t base = (size_t)t * W;
+    const int nslots = nranks * per;
+    for (int pos = threadIdx.x; pos < W; pos += 256) {
+        const int wl = b.order[base + pos], cl = b.cw[base + pos];
+        const int split = pos >= n0;
+        int off[2];
+        for (int which = 0; which < 2; ++which) {
+            const int version = which ? t + split : t, xl = which ? cl : wl;
+            off[which] = -1;
+            if (version > 0) {
+                const int pp = b.pos_of[(size_t)(version - 1) * W + xl];
+                const int set = pp >= n0, hp = 2 * (version - 1) + set, ph = pp - set * n0;
+                off[which] = (hp * nslots + shard_slot(ph, set ? W - n0 : n0, nranks, per)) * row;
+            }
+        }
+        b.link[2 * (base + pos)] = (unsigned long long)(unsigned)off[0] | ((unsigned long long)(unsigned)off[1] << 32);
+    }
 }
 
+// After the K steps of a chunk: the (thinned) chain, the acceptance counters and the final state, gathered from the history.
+// One thread per (step, walker): the walker's row of that step sits where its position in the step's lists says.
 __global__ void __launch_bounds__(256)
-shard_nacc_kernel(const long long* __restrict__ all, int nranks, int W, long long* __restrict__ n_accept) {
-    const int w = blockIdx.x * 256 + threadIdx.x;
-    if (w >= W) return;
-    long long s = 0;
-    for (int r = 0; r < nranks; ++r) s += all[(size_t)r * W + w];
-    n_accept[w] += s;
+shard_chain_kernel(const int* __restrict__ pos_of, const double* __restrict__ shist, int K, int W, int d, int n0, int nranks, int per,
+                   int thin_by, long long done0, double* __restrict__ chain, double* __restrict__ chain_logp,
+                   unsigned long long* __restrict__ n_accept, double* __restrict__ coords, double* __restrict__ logp) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)K * W) return;
+    const int t = (int)(i / W), w = (int)(i % W), row = d + 2, nslots = nranks * per;
+    const int pp = pos_of[(size_t)t * W + w];
+    const int set = pp >= n0, ph = pp - set * n0;
+    const double* r = shist + ((size_t)(2 * t + set) * nslots + shard_slot(ph, set ? W - n0 : n0, nranks, per)) * row;
+    if (n_accept && r[d + 1] != 0.0) atomicAdd(n_accept + w, 1ull);
+    const long long done = done0 + t + 1;
+    if (done % thin_by == 0) {
+        const size_t slot = (size_t)(done / thin_by - 1);
+        if (chain) for (int k = 0; k < d; ++k) chain[(slot * W + w) * d + k] = r[k];
+        if (chain_logp) chain_logp[slot * W + w] = r[d];
+    }
+    if (t == K - 1) {
+        for (int k = 0; k < d; ++k) coords[(size_t)w * d + k] = r[k];
+        logp[w] = r[d];
+    }
 }
 
 static int all_gather(alabi_comm* c, const double* send, double* recv, size_t count, hipStream_t s) {
     if (c->nranks == 1 && !c->nccl) {
-        ALABI_HIP_CHECK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if (recv != send) ALABI_HIP_CHECK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
         return ALABI_OK;
     }
     if (c->fn) return c->fn(send, recv, (long long)count, c->user, reinterpret_cast<void*>(s)) == 0 ? ALABI_OK : ALABI_HIP_ERROR;
@@ -168,11 +190,36 @@ int alabi_dist_comm_create_callback(alabi_allgather_fn fn, void* user, int rank,
 int alabi_dist_comm_destroy(alabi_comm* c) {
     if (!c) return ALABI_OK;
     if (c->nccl && rccl().ok) (void)rccl().CommDestroy(c->nccl);
-    if (c->send) (void)hipFree(c->send);
-    if (c->recv) (void)hipFree(c->recv);
-    if (c->nacc_local) (void)hipFree(c->nacc_local);
-    if (c->nacc_all) (void)hipFree(c->nacc_all);
+    if (c->graph) (void)hipGraphExecDestroy(c->graph);
+    if (c->shist) (void)hipFree(c->shist);
     delete c;
+    return ALABI_OK;
+}
+
+// the enqueues of one chunk of K steps whose records are in the draw buffers: link records, 2 K x (half-step kernel on this
+// rank's slice + in-place all-gather), the gather of chain / counters / final state
+static int enqueue_sharded_chunk(alabi_ens* e, alabi_comm* c, double* coords, double* logp, int K, int thin_by, long long done0,
+                                 double* chain, double* chain_logp, long long* n_accept, hipStream_t s) {
+    const int W = e->W, d = e->d, n0 = (W + 1) / 2, row = d + 2;
+    const int per = (n0 + c->nranks - 1) / c->nranks;
+    const size_t block = (size_t)c->nranks * per * row;                 // doubles per half step
+    hipLaunchKernelGGL(shard_link_kernel, dim3(K), dim3(256), 0, s, e->draws, W, n0, c->nranks, per, row);
+    int st;
+    for (int t = 0; t < K; ++t)
+        for (int split = 0; split < 2; ++split) {
+            const int nS = split == 0 ? n0 : W - n0;
+            if (nS == 0) continue;
+            int b, en;
+            slice_bounds(nS, c->nranks, c->rank, &b, &en);
+            double* blk = c->shist + (size_t)(2 * t + split) * block;
+            double* mine = blk + (size_t)c->rank * per * row;
+            if (en > b && (st = alabi_ens_half_step_hist(e, coords, logp, t, split, b, en, c->shist, mine, s)) != ALABI_OK) return st;
+            if ((c->nranks > 1 || c->nccl) && (st = all_gather(c, mine, blk, (size_t)per * row, s)) != ALABI_OK) return st;
+        }
+    hipLaunchKernelGGL(shard_chain_kernel, dim3((unsigned)(((long long)K * W + 255) / 256)), dim3(256), 0, s, e->draws.pos_of, c->shist, K, W,
+                       d, n0, c->nranks, per, thin_by, done0, chain, chain_logp,
+                       reinterpret_cast<unsigned long long*>(n_accept), coords, logp);
+    ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }
 
@@ -182,64 +229,63 @@ int alabi_ens_run_sharded(alabi_ens* e, alabi_comm* c, double* coords, double* l
     if (!e->gp->computed || !e->gp->has_alpha) return ALABI_NOT_COMPUTED;
     if (nsteps == 0) return ALABI_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int W = e->W, d = e->d, n0 = (W + 1) / 2, row = d + 1;
+    const int W = e->W, d = e->d, n0 = (W + 1) / 2, row = d + 2;
     const int per = (n0 + c->nranks - 1) / c->nranks;                    // equal slots (the larger half decides)
-    const size_t send_n = (size_t)per * row, recv_n = send_n * c->nranks;
-    if (c->send_cap < send_n) {
-        if (c->send) (void)hipFree(c->send);
-        ALABI_HIP_CHECK(hipMalloc(&c->send, send_n * sizeof(double))); c->send_cap = send_n;
-        ALABI_HIP_CHECK(hipMemsetAsync(c->send, 0, send_n * sizeof(double), s));
+    const size_t need = (size_t)2 * e->chunk_cap * c->nranks * per * row;
+    if ((size_t)2 * e->chunk_cap * c->nranks * per * row > 0x7fffffffull) return ALABI_BAD_ARGUMENT;   // 32-bit word offsets in the link records
+    if (c->shist_cap < need) {
+        if (c->shist) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(c->shist); c->shist = nullptr; c->shist_cap = 0; }
+        if (c->graph) { (void)hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+        ALABI_HIP_CHECK(hipMalloc(&c->shist, need * sizeof(double)));
+        ALABI_HIP_CHECK(hipMemsetAsync(c->shist, 0, need * sizeof(double), s));   // slots beyond a rank's share travel in the all-gather
+        c->shist_cap = need;
     }
-    if (c->recv_cap < recv_n) {
-        if (c->recv) (void)hipFree(c->recv);
-        ALABI_HIP_CHECK(hipMalloc(&c->recv, recv_n * sizeof(double))); c->recv_cap = recv_n;
-    }
-    if (c->nacc_cap < (size_t)W) {
-        if (c->nacc_local) (void)hipFree(c->nacc_local);
-        if (c->nacc_all) (void)hipFree(c->nacc_all);
-        ALABI_HIP_CHECK(hipMalloc(&c->nacc_local, (size_t)W * sizeof(long long)));
-        ALABI_HIP_CHECK(hipMalloc(&c->nacc_all, (size_t)W * c->nranks * sizeof(long long)));
-        c->nacc_cap = (size_t)W;
-    }
-    ALABI_HIP_CHECK(hipMemsetAsync(c->nacc_local, 0, (size_t)W * sizeof(long long), s));
+    // a graph of one full chunk, where everything it enqueues can be captured (RCCL, or no collective at all); the host callback
+    // of the test rig cannot
+    const char* genv = getenv("ALABI_ENS_GRAPH");
+    const bool want_graph = s != nullptr && !c->fn && !(genv && genv[0] == '0');
     int st;
+    if ((st = ens_sync_consts(e, s)) != ALABI_OK) return st;      // (a host copy + synchronisation: not inside a capture)
     long long done = 0;
     while (done < nsteps) {
         const int K = (int)((nsteps - done) < e->chunk_cap ? (nsteps - done) : e->chunk_cap);
         if ((st = alabi_ens_draw(e, step0 + done, K, a, stream)) != ALABI_OK) return st;   // records of the chunk, identical on every rank
-        for (int t = 0; t < K; ++t) {
-            const int* order = e->draws.order + (size_t)t * W;
-            for (int split = 0; split < 2; ++split) {
-                const int nS = split == 0 ? n0 : W - n0;
-                if (nS == 0) continue;
-                int b, en;
-                slice_bounds(nS, c->nranks, c->rank, &b, &en);
-                if (en > b && (st = alabi_ens_half_step(e, coords, logp, t, split, b, en, c->nacc_local, stream)) != ALABI_OK) return st;
-                if (c->nranks > 1 || c->nccl) {
-                    const int* list = order + (split ? n0 : 0);
-                    if (en > b)
-                        hipLaunchKernelGGL(shard_pack_kernel, dim3(((en - b) * row + 255) / 256), dim3(256), 0, s, list, b, en, d, coords,
-                                           logp, c->send);
-                    if ((st = all_gather(c, c->send, c->recv, send_n, s)) != ALABI_OK) return st;
-                    hipLaunchKernelGGL(shard_unpack_kernel, dim3((nS * row + 255) / 256), dim3(256), 0, s, list, nS, c->nranks, c->rank,
-                                       per, d, c->recv, coords, logp);
+        // a full chunk replays the captured graph (link records, half steps, all-gathers, final state); the chain rows and the
+        // counters, whose place depends on how far the run is, are gathered by one more launch behind it
+        if (want_graph && K == e->chunk_cap) {
+            alabi_comm::Key key{e, coords, logp, K, a, e->gp->gen};
+            const bool same = c->graph && memcmp(&key, &c->key, sizeof(key)) == 0;
+            if (!same) {
+                if (c->graph) { (void)hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+                hipGraph_t g = nullptr;
+                ALABI_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                st = enqueue_sharded_chunk(e, c, coords, logp, K, 1, 0, nullptr, nullptr, nullptr, s);
+                const hipError_t ce = hipStreamEndCapture(s, &g);
+                if (st != ALABI_OK || ce != hipSuccess) {
+                    if (g) (void)hipGraphDestroy(g);
+                    (void)hipGetLastError();
+                    if (st != ALABI_OK) return st;
+                } else {
+                    const hipError_t ie = hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(g);
+                    if (ie != hipSuccess) { (void)hipGetLastError(); c->graph = nullptr; }
+                    else c->key = key;
                 }
             }
-            const long long k = done + t + 1;
-            if ((chain || chain_logp) && k % thin_by == 0) {
-                const size_t slot = (size_t)(k / thin_by - 1);
-                hipLaunchKernelGGL(shard_store_kernel, dim3((W * d + 255) / 256), dim3(256), 0, s, coords, logp, W, d,
-                                   chain ? chain + slot * W * d : nullptr, chain_logp ? chain_logp + slot * W : nullptr);
+            if (c->graph) {
+                ALABI_HIP_CHECK(hipGraphLaunch(c->graph, s));
+                if (chain || chain_logp || n_accept) {
+                    hipLaunchKernelGGL(shard_chain_kernel, dim3((unsigned)(((long long)K * W + 255) / 256)), dim3(256), 0, s, e->draws.pos_of,
+                                       c->shist, K, W, d, n0, c->nranks, per, thin_by, done, chain, chain_logp,
+                                       reinterpret_cast<unsigned long long*>(n_accept), coords, logp);
+                    ALABI_LAUNCH_CHECK();
+                }
+                done += K;
+                continue;
             }
         }
-        ALABI_LAUNCH_CHECK();
+        if ((st = enqueue_sharded_chunk(e, c, coords, logp, K, thin_by, done, chain, chain_logp, n_accept, s)) != ALABI_OK) return st;
         done += K;
-    }
-    if (n_accept) {   // every walker was counted by exactly one rank
-        if ((st = all_gather(c, reinterpret_cast<const double*>(c->nacc_local), reinterpret_cast<double*>(c->nacc_all), (size_t)W, s)) != ALABI_OK)
-            return st;
-        hipLaunchKernelGGL(shard_nacc_kernel, dim3((W + 255) / 256), dim3(256), 0, s, c->nacc_all, c->nranks, W, n_accept);
-        ALABI_LAUNCH_CHECK();
     }
     return ALABI_OK;
 }

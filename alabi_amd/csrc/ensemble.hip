@@ -198,8 +198,18 @@ ens_half_kernel(HalfArgs p) {
     if (w < 0) return;  // inert record (range-checked test input); workgroup-uniform
     const int cw = p.rec.cw[pos];
     const double zz = p.rec.zz[pos];
+    // where the two rows live: in place (coords / logp), or -- sharded ensemble -- in the history of published rows
+    const double* own_c = p.coords + (size_t)w * p.d;
+    const double* own_lp = p.logp + w;
+    const double* par_c = p.coords + (size_t)cw * p.d;
+    if (p.shist) {
+        const unsigned long long lw = p.rec.link[2 * pos];
+        const int so = (int)(unsigned)(lw & 0xffffffffull), sp = (int)(unsigned)(lw >> 32);
+        if (so >= 0) { own_c = p.shist + so; own_lp = own_c + p.d; }
+        if (sp >= 0) par_c = p.shist + sp;
+    }
     double lp_old = 0.0, lnfac = 0.0, lnu = 0.0;
-    if (tid < 64) { lp_old = p.logp[w]; lnfac = p.rec.lnfac[pos]; lnu = p.rec.lnu[pos]; }  // wave 0 decides
+    if (tid < 64) { lp_old = *own_lp; lnfac = p.rec.lnfac[pos]; lnu = p.rec.lnu[pos]; }  // wave 0 decides
     const double* inv_len = p.consts;
     const double* lo = p.consts + ALABI_MAX_DIM;
     const double* hi = p.consts + 2 * ALABI_MAX_DIM;
@@ -207,8 +217,8 @@ ens_half_kernel(HalfArgs p) {
     if (tid < D) {
         double qv = 0.0;
         if (tid < p.d) {
-            const double cv = p.coords[(size_t)cw * p.d + tid];
-            const double sv = p.coords[(size_t)w * p.d + tid];
+            const double cv = par_c[tid];
+            const double sv = own_c[tid];
             qv = cv - (cv - sv) * zz;
             ok = (qv > lo[tid]) && (qv < hi[tid]);
             q_s[tid] = qv; old_s[tid] = sv;
@@ -262,6 +272,12 @@ ens_half_kernel(HalfArgs p) {
     }
     // (4) wave 0: accept test in every lane (same inputs), first d lanes write the state
     const int acc_flag = (lnfac + lp_new - lp_old > lnu) ? 1 : 0;
+    if (p.sout) {                                          // sharded ensemble: the new row goes to the history, nothing else is written
+        double* o = p.sout + (size_t)blockIdx.x * (p.d + 2);
+        if (tid < p.d) o[tid] = acc_flag ? q_s[tid] : old_s[tid];
+        if (tid == 0) { o[p.d] = acc_flag ? lp_new : lp_old; o[p.d + 1] = acc_flag ? 1.0 : 0.0; }
+        return;
+    }
     if (acc_flag) {
         if (tid < p.d) p.coords[(size_t)w * p.d + tid] = q_s[tid];
         if (tid == 0) {
@@ -959,7 +975,7 @@ int launch_ens_half_args(alabi_ens* e, const HalfArgs& args_in, int nblocks, hip
     const long long total = (long long)nblocks * e->E;
     const char* env = getenv("ALABI_ENS_MULTI");
     int np = 1;
-    if (threads <= 512 && db <= 24 && !(env && env[0] == '0')) {
+    if (threads <= 512 && db <= 24 && !(env && env[0] == '0') && !args.shist) {
         if (total > 3LL * n_cu && db <= 16) np = 4; else if (total > n_cu) np = 2;   // q[NP][D] lives in registers
         if (env && env[0] == '4' && db <= 16) np = 4;
         if (env && env[0] == '2') np = 2;

@@ -137,8 +137,9 @@ class ShardedEnsemble:
 
 class ShardedRun:
     """The same sharded ensemble with the WHOLE step loop inside the library (alabi_ens_run_sharded): per half step the
-    half-step kernel on this rank's slice, a pack kernel, ONE all-gather and an unpack kernel, all enqueued on the stream --
-    no host read-back between half steps.  The all-gather is RCCL's ncclAllGather on a communicator the library creates
+    half-step kernel on this rank's slice writes its new rows straight into the rank's segment of a history block and ONE
+    in-place all-gather completes the block -- two enqueues per half step, no pack / unpack kernels, no host read-back; a
+    full chunk of steps is one hipGraph replay (RCCL or single rank).  The all-gather is RCCL's ncclAllGather on a communicator the library creates
     itself (rank 0 draws the unique id, torch.distributed only broadcasts its 128 bytes); under a "gloo" process group
     (test rig: several ranks on ONE GPU, which RCCL refuses) a host callback stands in for it."""
 
@@ -152,6 +153,7 @@ class ShardedRun:
         lib = _lib.lib()
         comm = C.c_void_p()
         self._cb = None
+        self.last_callback_error = None
         if self.world > 1 and dist.get_backend(group) != "nccl":
             hip = C.CDLL("libamdhip64.so")
             hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -168,7 +170,8 @@ class ShardedRun:
                     dist.all_gather_into_tensor(out, torch.from_numpy(h), group=group)
                     o = out.numpy()
                     return 0 if hip.hipMemcpy(C.c_void_p(recv), o.ctypes.data_as(C.c_void_p), world * count * 8, 1) == 0 else 1
-                except Exception:  # noqa: BLE001
+                except Exception as ex:  # noqa: BLE001  (no exception may cross the C boundary: keep its text for the caller)
+                    self.last_callback_error = repr(ex)
                     return 1
             self._cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p)(_allgather)
             _lib.check(lib.alabi_dist_comm_create_callback(C.cast(self._cb, C.c_void_p), None, self.rank, self.world,
@@ -210,6 +213,8 @@ class ShardedRun:
         st = _lib.lib().alabi_ens_run_sharded(self.s._ens, self._comm, _lib.ptr(coords), _lib.ptr(logp), int(step0), int(nsteps),
                                               int(thin_by), float(a), _lib.ptr(chain), None, _lib.ptr(n_accept),
                                               _lib.current_stream())
+        if st != 0 and self.last_callback_error:
+            raise RuntimeError(f"alabi_ens_run_sharded: the all-gather callback failed: {self.last_callback_error}")
         _lib.check(st, "alabi_ens_run_sharded")
         return chain, coords, logp, n_accept
 

@@ -346,12 +346,22 @@ def main():
 
     shard = args.mode == "shard" and use_dist
     if shard:
-        from alabi_amd.dist import ShardedRun
+        from alabi_amd.dist import HipBackend, ShardedEnsemble, ShardedRun
         Wtot = W * world
         rngp = np.random.RandomState(1000 + d)
         p0 = rngp.uniform(cfg["bounds"][:, 0] * 0.5, cfg["bounds"][:, 1] * 0.5, (Wtot, d))
         sampler = EnsembleSampler(Wtot, d, gp, cfg["y"], cfg["bounds"], seed=2026)
-        ens = ShardedRun(sampler)          # the whole step loop in the library, one ncclAllGather per half step on the stream
+        # the whole step loop in the library, one in-place ncclAllGather per half step on the stream; ALABI_BENCH_SHARD_IMPL=python
+        # selects the Python loop around alabi_ens_half_step + torch.distributed (the implementation the gloo tests exercise)
+        if os.environ.get("ALABI_BENCH_SHARD_IMPL") == "python":
+            _py = ShardedEnsemble(HipBackend(sampler))
+
+            class _Ens:
+                def run(self, coords, nsteps, step0=0, store=True):
+                    return _py.run(coords, nsteps, step0=step0)
+            ens = _Ens()
+        else:
+            ens = ShardedRun(sampler)
         state = {"coords": torch.as_tensor(p0, device="cuda"), "step": 0}
 
         def one_step():

@@ -95,6 +95,13 @@ def test_sharded_run_single_rank_and_rccl_loads(monkeypatch):
     chain2, _, _, nacc2 = run2.run(torch.as_tensor(p0, device="cuda"), nsteps, thin_by=3)
     torch.cuda.synchronize()
     assert np.array_equal(chain2.cpu().numpy(), ref.get_chain()) and np.array_equal(nacc2.cpu().numpy(), nacc.cpu().numpy())
+    # two full chunks (1024 steps each: the captured graph is replayed) plus a remainder, thinned chain, RCCL communicator
+    ref3 = EnsembleSampler(W, 4, gp, y, bounds, seed=5); ref3.run_mcmc(p0, 2100, thin_by=7)
+    s3 = EnsembleSampler(W, 4, gp, y, bounds, seed=5)
+    chain3, coords3, logp3, nacc3 = run2.__class__(s3).run(torch.as_tensor(p0, device="cuda"), 2100, thin_by=7)
+    assert np.array_equal(chain3.cpu().numpy(), ref3.get_chain())
+    assert np.array_equal(nacc3.cpu().numpy(), ref3._naccept.cpu().numpy())
+    assert np.array_equal(coords3.cpu().numpy(), ref3.get_last_sample().coords)
     del run2
     buf = C.create_string_buffer(128)
     _lib.check(_lib.lib().alabi_dist_unique_id(buf), "alabi_dist_unique_id")
