@@ -839,7 +839,7 @@ class SurrogateModel(object):
         use_bounds = method.lower() in ("nelder-mead", "l-bfgs-b", "tnc", "powell", "slsqp", "trust-constr")
         for x0 in starts[:max(int(nRestarts), 1)]:
             try:
-                res = op.minimize(lambda x: -lnp(x) if np.isfinite(lnp(x)) else 1e25, x0, method=method, options=options,
+                res = op.minimize(lambda x: (lambda v: -v if np.isfinite(v) else 1e25)(lnp(x)), x0, method=method, options=options,
                                   bounds=list(zip(lo + eps, hi - eps)) if use_bounds else None)
             except Exception:  # noqa: BLE001
                 continue

@@ -90,6 +90,10 @@ __device__ inline double row16_allsum(double v) {
     return v;
 }
 
+// Value of lane ^ 16 (the other 16-lane row of a 32-lane slot): ds_swizzle in bit mode, and 0x1f / or 0 / xor 0x10
+__device__ inline int swz16(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x401F); }
+__device__ inline double swz16(double v) { return __hiloint2double(swz16(__double2hiint(v)), swz16(__double2loint(v))); }
+
 // Sum of the G partial sums of a proposal, one per lane of an aligned segment of G = 8 or 16 lanes; result in every lane of the
 // segment.  THE summation order of the members' partials: every reader of a row uses this tree, so all of them (and the tail
 // pass that writes the chain) repeat the accept test on identical bits.
@@ -404,8 +408,8 @@ ens_group_kernel(GroupArgs p) {
                 o_acc = __builtin_amdgcn_update_dpp(0, accf, 0x128, 0xf, 0xf, true);   // row_ror:8
                 o_lp = dpp_move<0x128, 0xf>(lp_sel);
             } else {
-                o_acc = __shfl_xor(accf, 16, 64);
-                o_lp = __shfl_xor(lp_sel, 16, 64);
+                o_acc = swz16(accf);
+                o_lp = swz16(lp_sel);
             }
             const int flag_o = seg ? o_acc : accf, flag_p = seg ? accf : o_acc;
             const double lp_o = seg ? o_lp : lp_sel;
@@ -454,8 +458,8 @@ ens_group_kernel(GroupArgs p) {
                 pr = row16_allsum(-0.5 * tt * tt);
             }
             if (LPR == 32) {
-                qq += __shfl_xor(qq, 16, 64);
-                if (p.has_prior) pr += __shfl_xor(pr, 16, 64);
+                qq += swz16(qq);
+                if (p.has_prior) pr += swz16(pr);
             }
             if (valid && k < KP)
                 aop[pp * KP + k] = (k < d) ? qs * SC : (k == d) ? SC : (k == d + 1) ? -0.5 * qq * SC : 0.0;
@@ -487,6 +491,8 @@ ens_group_kernel(GroupArgs p) {
             for (int jj = 0; jj < NRL; ++jj) pend[jj] = (lane + jj * 64 < RW) ? rec_load(hh + 3, lane + jj * 64) : 0ull;
         }
         // ---- phase 2: kernel sums of the QP proposals over this member's slice, on the matrix cores ----
+        // (waves w and w + 4 share a SIMD; w finishes its sums 15-20 % before w + 4.  Raising the younger wave's s_setprio for
+        // the phase was measured and changes nothing: 5.06 / 24.5 us per half step at C4 / C5-sized either way.)
         double a[Q][KS];
 #pragma unroll
         for (int qt = 0; qt < Q; ++qt)

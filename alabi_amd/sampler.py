@@ -156,6 +156,8 @@ class EnsembleSampler:
 
     def __setstate__(self, st):
         self.__dict__.update(st)
+        if "_rng_step" not in st:                       # saved before the draw counter was separated from `iteration`
+            self._rng_step = st.get("iteration", 0)
         if torch.cuda.is_available():
             self._stream = torch.cuda.Stream()
             for k in ("_coords", "_logp", "_naccept"):
@@ -212,9 +214,14 @@ class EnsembleSampler:
         dev = self._coords.device
         stream = _lib.current_stream()
         want_like = self.like_fn_host is None
+        if self.prior_fn_host is None and self.like_fn_host is None:
+            raise RuntimeError("this sampler was set up with host callables (prior_fn / like_fn) that are not part of its "
+                               "saved state: create a new sampler with them")
+        # steps per draw: at most the library's draw-buffer chunk (4M / walkers, between 16 and 1024 steps)
+        cap = max(16, min(1024, (4 << 20) // max(self.total_walkers, 1)))
         done = 0
         while done < nsteps:
-            n = min(256, nsteps - done)
+            n = min(256, cap, nsteps - done)
             _lib.check(lib.alabi_ens_draw(self._ens, self._rng_step + done, n, self.a, stream), "alabi_ens_draw")
             for t in range(n):
                 for split in (0, 1):
