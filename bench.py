@@ -143,16 +143,16 @@ def cpu_baseline(cfg, budget_s=10.0, cores=1):
 
 def pmc_summary(prefix, which="max"):
     """Counters of the kernel whose name starts with `prefix` from the committed PMC passes of this round
-    (profiles/r02_pmc_by_kernel.json: rocprofv3 --pmc runs of this same bench command, tools/collect_profiles.sh).
+    (profiles/r03_pmc_by_kernel.json: rocprofv3 --pmc runs of this same bench command, tools/collect_profiles.sh).
     FETCH_SIZE is doubled (16-byte-per-lane streaming reads are tallied at half their bytes on gfx950,
     MI355X_MICROARCH.md section HBM) unless the kernel's fetches are 8-byte polls.  None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_by_kernel.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_by_kernel.json")
     if not os.path.exists(path):
         return None
     try:
         allk = json.load(open(path))
         v = next(v for k, v in allk.items() if k.replace("void ", "").startswith("alabi::" + prefix))
-        out = {"source": "profiles/r02_pmc_by_kernel.json", "statistic": which + " over the launches of the profiled run"}
+        out = {"source": "profiles/r03_pmc_by_kernel.json", "statistic": which + " over the launches of the profiled run"}
         for c, key in (("FETCH_SIZE", "fetch_KB"), ("WRITE_SIZE", "write_KB"), ("SQ_INSTS_VALU_MFMA_F64", "mfma_f64_instructions"),
                        ("SQ_VALU_MFMA_BUSY_CYCLES", "mfma_busy_cycles_summed_over_simds"), ("SQ_VALU_MFMA_COEXEC_CYCLES", "valu_mfma_coexec_cycles"),
                        ("SQ_INSTS_VALU", "valu_instructions"), ("SQ_WAVE_CYCLES", "wave_quad_cycles"), ("SQ_WAIT_ANY", "wait_any_quad_cycles"),
@@ -238,6 +238,8 @@ def config_extras():
             # algorithmic fp64 work of the kernel sums: W/2 proposals x N points x (2d + 3) per half step
             entry["tflops"] = (cfg["W"] / 2.0) * cfg["N"] * (2 * cfg["d"] + 3) / (entry["us_per_half_step"] * 1e-6) / 1e12
             entry["roofline_frac_fp64"] = entry["tflops"] / FP64_PEAK_TFLOPS
+            if s.last_stream_kernel == "ens_group_kernel":     # counters of the committed PMC passes (same bench command)
+                entry["counters"] = pmc_summary("ens_group_kernel<%d," % ((cfg["d"] + 2 + 3) // 4))
             if name == "C5":
                 gen = torch.Generator(device="cuda"); gen.manual_seed(6)
                 lo = torch.as_tensor(cfg["bounds"][:, 0], device="cuda"); hi = torch.as_tensor(cfg["bounds"][:, 1], device="cuda")
@@ -471,7 +473,7 @@ def main():
         # MI355X_MICROARCH.md section HBM).  A PMC pass cannot run inside this process, so the number is read from
         # profiles/ and is null when the file is absent or the workload differs from the profiled one.
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_by_kernel.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_by_kernel.json")
         if os.path.exists(pmc_path) and args.config == "C3" and args.ensembles == 1 and not shard:
             try:
                 allk = json.load(open(pmc_path))
