@@ -257,7 +257,10 @@ ens_group_kernel(GroupArgs p) {
 #pragma unroll
     for (int ps = 0; ps < NPM; ++ps) {
         const int pp = ps * PPP + pwv * PPW + pl;
-        mine_[ps] = (pp % G) == m;
+        // member (pp + PPW (pp / G)) mod G publishes proposal pp: the proposals of one member sit in slots of DIFFERENT waves
+        // (with pp mod G they were all in one wave's slot, and that wave's candidate / chain stores set the pace of the row
+        // phase: 4.8 -> 2.9 us of accept tests + proposals at C5 size)
+        mine_[ps] = ((pp + PPW * (pp / G)) % G) == m;
         cand_off_[ps] = (g * p.QP + pp) * CW;
     }
 
@@ -492,7 +495,9 @@ ens_group_kernel(GroupArgs p) {
         }
         // ---- phase 2: kernel sums of the QP proposals over this member's slice, on the matrix cores ----
         // (waves w and w + 4 share a SIMD; w finishes its sums 15-20 % before w + 4.  Raising the younger wave's s_setprio for
-        // the phase was measured and changes nothing: 5.06 / 24.5 us per half step at C4 / C5-sized either way.)
+        // the phase was measured and changes nothing: 5.06 / 24.5 us per half step at C4 / C5-sized either way; neither does
+        // giving the older wave 55 % of the pair's tile products: the sums then end together, 15.0 / 14.0 instead of 15.6 / 12.8 us
+        // at C5 size, but the half step gains 0.1 us -- the SIMD's fp64 pipe is simply busy for that long.)
         double a[Q][KS];
 #pragma unroll
         for (int qt = 0; qt < Q; ++qt)

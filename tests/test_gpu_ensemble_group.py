@@ -85,6 +85,26 @@ def test_group_kernel_matches_half_step_path_and_continues(monkeypatch):
     assert np.array_equal(runs["half"][2], runs["group"][2])
 
 
+def test_group_kernel_across_chunks(monkeypatch):
+    """More steps than one launch covers (1024): two full chunks and a remainder, the state carried from launch to launch
+    through hist row 0; chain, log-probabilities and acceptance counters against the launch-per-half-step kernels."""
+    from alabi_amd import EnsembleSampler
+    g, o, y = _pair(700, 4, 19, ell2=7.0)
+    bounds = np.array([[-3.0, 3.0]] * 4)
+    W = 36
+    p0 = np.random.RandomState(4).uniform(-2, 2, (W, 4))
+    out = {}
+    for tag, env in (("half", {"ALABI_ENS_STREAM": "0"}), ("group", {"ALABI_ENS_STREAM": "1", "ALABI_ENS_GROUP": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = EnsembleSampler(W, 4, g, y, bounds, seed=8)
+        s.run_mcmc(p0, 2300, thin_by=5)
+        out[tag] = (s.get_chain(), s.get_log_prob(), s._naccept.cpu().numpy().copy(), s.last_path)
+    assert out["group"][3] == "group" and out["group"][0].shape == (460, W, 4)
+    assert np.max(np.abs(out["half"][0] - out["group"][0])) <= 1e-7
+    assert np.array_equal(out["half"][2], out["group"][2])
+
+
 def test_group_kernel_normal_prior_and_affine_logp(monkeypatch):
     """lnprior_normal on two coordinates + an affine y scaler folded into amplitude and mean (alabi/utility.py:370,
     alabi/core.py:1483-1502), group kernel against the launch-per-half-step kernels."""
