@@ -75,45 +75,84 @@ __device__ inline void write_record(const DrawBuffers& b, size_t pos, int wid, i
     pk[3] = (unsigned long long)__double_as_longlong(lnu);
 }
 
-// grid = (steps of the chunk, ensembles); dynamic LDS = W * (8 + 4 + 4) bytes.
+// grid = (steps of the chunk, ensembles); dynamic LDS = Wp * 12 + 1024 bytes, Wp = W rounded up to a power of two.
+// The rank of a walker's key among the step's keys (ties by walker id) decides its label: a bitonic sort of (key, id) pairs in
+// LDS -- O(W log^2 W) compare-exchanges instead of the W^2 comparisons of the first version (0.21 ms per 1024-step chunk at
+// 1024 walkers, 0.62 ms at 2048: 4 % of the C4 run) -- then the two ordered lists by a prefix count over the labels.
 __global__ void __launch_bounds__(256)
-ens_draw_kernel(unsigned long long seed, const long long* __restrict__ run_state, int W, int d, double a,
+ens_draw_kernel(unsigned long long seed, const long long* __restrict__ run_state, int W, int Wp, int d, double a,
                 DrawBuffers b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-    int* label = reinterpret_cast<int*>(smem + (size_t)W * 8);
-    int* olist = label + W;   // local ids in list order (set 0 then set 1)
-    const int E = gridDim.y, e = blockIdx.y;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                       // [Wp]; after the sort: label[W], olist[W]
+    uint32_t* ids = reinterpret_cast<uint32_t*>(smem + (size_t)Wp * 8);       // [Wp]
+    int* scan = reinterpret_cast<int*>(smem + (size_t)Wp * 12);               // [256]
+    const int E = gridDim.y, e = blockIdx.y, tid = threadIdx.x;
     const long long step = run_state[0] + blockIdx.x;
     const uint32_t s_lo = (uint32_t)step, s_hi = (uint32_t)((unsigned long long)step >> 32);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const size_t base = ((size_t)blockIdx.x * E + e) * W;
     const uint32_t g0 = (uint32_t)e * (uint32_t)W;  // global id of this ensemble's walker 0
     uint32_t r[4];
-    for (int i = threadIdx.x; i < W; i += 256) {
-        philox4x32_10(s_lo, s_hi, g0 + (uint32_t)i, 0u, k0, k1, r);
-        keys[i] = ((uint64_t)r[0] << 32) | r[1];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < W; i += 256) {
-        const uint64_t ki = keys[i];
-        int rank = 0;
-        for (int j = 0; j < W; ++j) {
-            const uint64_t kj = keys[j];
-            rank += (kj < ki) || (kj == ki && j < i);
+    for (int i = tid; i < Wp; i += 256) {
+        uint64_t key = ~0ull;                                                 // padding sorts behind every walker (ties by id)
+        if (i < W) {
+            philox4x32_10(s_lo, s_hi, g0 + (uint32_t)i, 0u, k0, k1, r);
+            key = ((uint64_t)r[0] << 32) | r[1];
         }
-        label[i] = rank & 1;
+        keys[i] = key; ids[i] = (uint32_t)i;
     }
     __syncthreads();
+    for (int k = 2; k <= Wp; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < Wp; t += 256) {
+                const int x = t ^ j;
+                if (x > t) {
+                    const uint64_t ka = keys[t], kb = keys[x];
+                    const uint32_t ia = ids[t], ib = ids[x];
+                    const bool gt = (ka > kb) || (ka == kb && ia > ib);
+                    if (gt == ((t & k) == 0)) { keys[t] = kb; keys[x] = ka; ids[t] = ib; ids[x] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    // rank of walker ids[t] is t: label = rank & 1 (`label` and `olist` reuse the keys' memory: the sort's last barrier is behind us)
+    int* label = reinterpret_cast<int*>(smem);
+    int* olist = label + W;   // local ids in list order (set 0 then set 1)
+    for (int t = tid; t < Wp; t += 256) {
+        const uint32_t i = ids[t];
+        if (i < (uint32_t)W) label[i] = t & 1;
+    }
+    __syncthreads();
+    // position of walker i inside its list = number of walkers j < i with the same label: every thread owns a run of
+    // consecutive walkers, the runs' label-0 counts are scanned by one wave
     const int n0 = (W + 1) / 2;
-    for (int i = threadIdx.x; i < W; i += 256) {
-        const int li = label[i];
-        int pos = 0;
-        for (int j = 0; j < i; ++j) pos += (label[j] == li);
-        olist[(li ? n0 : 0) + pos] = i;
+    const int per = (W + 255) / 256, i0 = tid * per, i1 = (i0 + per < W) ? i0 + per : W;
+    int zeros = 0;
+    for (int i = i0; i < i1; ++i) zeros += (label[i] == 0);
+    scan[tid] = zeros;
+    __syncthreads();
+    if (tid < 64) {
+        int v[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = scan[4 * tid + q]; tot += v[q]; }
+        int inc = tot;                                                        // inclusive scan over the 64 lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off, 64); if (tid >= off) inc += o; }
+        int run = inc - tot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { scan[4 * tid + q] = run; run += v[q]; }
     }
     __syncthreads();
-    for (int pos = threadIdx.x; pos < W; pos += 256) {
+    {
+        int z = scan[tid], o = i0 - z;                                        // label-0 / label-1 walkers before i0
+        for (int i = i0; i < i1; ++i) {
+            const int li = label[i];
+            const int pos = li ? o++ : z++;
+            olist[(li ? n0 : 0) + pos] = i;
+        }
+    }
+    __syncthreads();
+    for (int pos = tid; pos < W; pos += 256) {
         const int i = olist[pos];
         const int li = pos >= n0;
         philox4x32_10(s_lo, s_hi, g0 + (uint32_t)i, 1u, k0, k1, r);
@@ -944,8 +983,15 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
 }
 
 int launch_ens_draw(alabi_ens* e, int nsteps, double a, hipStream_t s) {
-    const size_t lds = (size_t)e->W * 16;
-    hipLaunchKernelGGL(ens_draw_kernel, dim3(nsteps, e->E), dim3(256), lds, s, e->seed, e->run_state, e->W, e->d, a,
+    int Wp = 1;
+    while (Wp < e->W) Wp <<= 1;
+    const size_t lds = (size_t)Wp * 12 + 1024;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        ALABI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ens_draw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ens_draw_kernel, dim3(nsteps, e->E), dim3(256), lds, s, e->seed, e->run_state, e->W, Wp, e->d, a,
                        e->draws);
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
