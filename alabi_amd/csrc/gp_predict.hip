@@ -899,12 +899,12 @@ __global__ void __launch_bounds__(256)
 predict_mean_mfma_kernel(const double* __restrict__ Xa, const double* __restrict__ alpha, int Npad,
                          const double* __restrict__ Xs, int d, long long M, DimVec inv_len, const double* __restrict__ centre,
                          double amp, double mean, KernelFn kf, double* __restrict__ mu) {
-    __shared__ double etab[64];                                  // 2^(j/64) for exp2s_tab64
-    if (threadIdx.x < 64) etab[threadIdx.x] = exp2((double)threadIdx.x * 0.015625);
+    __shared__ double etab[256];                                 // 2^(j/256) for exp2s_tab256
+    etab[threadIdx.x] = exp2((double)threadIdx.x * 0.00390625);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // squared exponential: the query operand carries the factor 64 / ln2, so the product arrives as the argument of 2^(./64)
-    const double qs = GENERIC ? 1.0 : ALABI_EXP2S_SCALE;
+    // squared exponential: the query operand carries the factor 256 / ln2, so the product arrives as the argument of 2^(./256)
+    const double qs = GENERIC ? 1.0 : ALABI_EXP2S256_SCALE;
     const int lr = lane & 15, lk = lane >> 4;
     const long long q0 = ((long long)blockIdx.x * 4 + wv) * 64;
     if (q0 >= M) return;
@@ -946,7 +946,7 @@ predict_mean_mfma_kernel(const double* __restrict__ Xa, const double* __restrict
             for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qt][s], b[s], acc, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                 // C/D layout: row (query) lk + 4 i, column (point) lr
-                const double f = GENERIC ? radial<true>(fmax(-2.0 * acc[i], 0.0), kf) : exp2s_tab64(acc[i], etab);
+                const double f = GENERIC ? radial<true>(fmax(-2.0 * acc[i], 0.0), kf) : exp2s_tab256(acc[i], etab);
                 sum[qt][i] = fma(al, f, sum[qt][i]);
             }
         }
