@@ -57,7 +57,8 @@ struct GroupArgs {
     const double* centre;                // [d] centre of the scaled training inputs
     const double* alpha;                 // [Npad]
     int K, W, n0, d, Npad;
-    int NG, QP, S;                       // groups, proposals per group and half step (16 Q), points per member (x16)
+    int NG, QP;                          // groups, proposals per group and half step (16 Q)
+    int tpm, ltw;                        // point tiles (of 16) per member; tiles per wave kept in LDS (the first RT of a wave's tiles are in registers)
     int xcd_map;                         // 1: members of a group share blockIdx % 8 (one XCD under round-robin placement; speed only)
     int spin_limit, has_prior;
     int poll_delay;                      // s_sleep(1) units (64 cycles) between barrier B and the first look at the fresh partial sums
@@ -97,12 +98,13 @@ __device__ inline double swz16(double v) { return __hiloint2double(swz16(__doubl
 // Sum of the G partial sums of a proposal, one per lane of an aligned segment of G = 8 or 16 lanes; result in every lane of the
 // segment.  THE summation order of the members' partials: every reader of a row uses this tree, so all of them (and the tail
 // pass that writes the chain) repeat the accept test on identical bits.
-template <int G>
+template <int G, int HALF>
 __device__ inline double seg_allsum(double v) {
     v += dpp_move<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
     v += dpp_move<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
     v += dpp_move<0x141, 0xf>(v);   // row_half_mirror
     if (G == 16) v += dpp_move<0x140, 0xf>(v);   // row_mirror
+    if (G == 8 && HALF == 16) v += dpp_move<0x128, 0xf>(v);   // 8 partials in the first 8 of the half's 16 lanes (the others hold 0): row_ror:8
     return v;
 }
 
@@ -137,11 +139,12 @@ ens_link_kernel(DrawBuffers b, int W, int n0, int NG, int QPAD, int G, int CW) {
 struct GroupLds {
     int etab, xb, al, aop, wsum, rec, ctl, total;
 };
-__host__ __device__ inline GroupLds group_lds(int KS, int QPAD, int S) {
+__host__ __device__ inline GroupLds group_lds(int KS, int QPAD, int lds_tiles) {
+    const int S = 16 * lds_tiles;
     GroupLds L;
     int o = 0;
     L.etab = o; o += 256;
-    L.xb = o; o += S * KS * 4;            // S/16 tiles x KS k-steps x 64 lanes
+    L.xb = o; o += S * KS * 4;            // lds_tiles (= 8 waves x tiles per wave in LDS) x KS k-steps x 64 lanes
     L.al = o; o += S;
     L.aop = o; o += QPAD * KS * 4;
     L.wsum = o; o += ALABI_GRP_NW * QPAD;
@@ -165,19 +168,22 @@ extern "C" int alabi_debug_group_prof(long long* out) {
 #endif
 
 // KS k-steps of the augmented dot product (d + 2 <= 4 KS), Q proposal tiles per group.  Rows have d + 2 <= 16 words for
-// KS <= 4 and <= 32 beyond: a proposal occupies LPR = 16 / 32 lanes in the row phase, and a group has G = LPR / 2 members, so
+// KS <= 4 and <= 32 beyond: a proposal occupies LPR = 16 / 32 lanes in the row phase, and a group has G <= LPR / 2 members, so
 // that the G partials of the own row and the G partials of the partner row of a proposal sit in the two halves of its lanes.
-template <int KS, int Q, bool GENERIC>
+// G = LPR / 2, or (G8: rows of 17..32 words, eight members) G = 8 with the first RT point tiles of every wave held in REGISTERS
+// for the whole launch: at d = 20, N = 10000 a member's slice of 79 tiles does not fit LDS (240 KB), and 16 members mean 64
+// proposals per group whose row phase takes four passes; with 8 members it is 32 proposals in two passes.
+template <int KS, int Q, bool G8, int RT, bool GENERIC>
 __global__ void __launch_bounds__(512)
 ens_group_kernel(GroupArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char grp_smem[];
     double* lds = reinterpret_cast<double*>(grp_smem);
     constexpr int QPAD = 16 * Q, KP = 4 * KS, NW = ALABI_GRP_NW;
-    constexpr int LPR = (KS <= 4) ? 16 : 32, LSH = (KS <= 4) ? 4 : 5, G = LPR / 2;
+    constexpr int LPR = (KS <= 4) ? 16 : 32, LSH = (KS <= 4) ? 4 : 5, HALF = LPR / 2, G = G8 ? 8 : HALF;
     constexpr int PPW = 64 / LPR, PPP = NW * PPW;            // proposals per wave / per pass over the workgroup
     constexpr int NPM = (QPAD + PPP - 1) / PPP;              // passes of the row phase
     constexpr int RW = 6 * QPAD;                             // ring words per half step
-    const GroupLds L = group_lds(KS, QPAD, p.S);
+    const GroupLds L = group_lds(KS, QPAD, NW * p.ltw);
     double* etab = lds + L.etab;
     double* xb = lds + L.xb;
     double* al_s = lds + L.al;
@@ -202,22 +208,40 @@ ens_group_kernel(GroupArgs p) {
         }
     }
     // ---- one-time set-up: the member's slice of Xa as B operands, alpha, the exp table, constants ----
+    // member m owns point tiles [m tpm, (m + 1) tpm) (clipped); wave wv of it the tiles [wv tpw, (wv + 1) tpw) of those: the first
+    // RT of a wave's tiles live in its registers, the others in LDS (ltw per wave)
     const int tiles_all = p.Npad >> 4;
-    const int tile0 = m * (p.S >> 4);
+    const int tile0 = m * p.tpm;
     int ntile = tiles_all - tile0;
-    if (ntile > (p.S >> 4)) ntile = p.S >> 4;
+    if (ntile > p.tpm) ntile = p.tpm;
     if (ntile < 0) ntile = 0;
-    for (int i = tid; i < ntile * KS * 64; i += 512) {
-        const int ln = i & 63, s = (i >> 6) % KS, tl = (i >> 6) / KS;
-        xb[i] = p.Xa[(size_t)(4 * s + (ln >> 4)) * p.Npad + (size_t)(tile0 + tl) * 16 + (ln & 15)];
+    const int tpw = (p.tpm + NW - 1) / NW;                   // (= RT + ltw when RT > 0)
+    int wcount = ntile - wv * tpw;                           // tiles of this wave
+    wcount = wcount < 0 ? 0 : (wcount > tpw ? tpw : wcount);
+    const int nreg = wcount < RT ? wcount : RT, nlds = wcount - nreg;
+    const int lr = lane & 15, lk = lane >> 4;
+    double xr[RT > 0 ? RT : 1][KS], ar[RT > 0 ? RT : 1];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const size_t pt = ((size_t)tile0 + wv * tpw + r) * 16 + lr;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) xr[r][s2] = (r < nreg) ? p.Xa[(size_t)(4 * s2 + lk) * p.Npad + pt] : 0.0;
+        ar[r] = (r < nreg) ? p.alpha[pt] : 0.0;
     }
-    for (int i = tid; i < ntile * 16; i += 512) al_s[i] = p.alpha[(size_t)tile0 * 16 + i];
+    for (int lt = 0; lt < p.ltw; ++lt) {                     // this wave's LDS tiles (zeros beyond its count: alpha = 0 adds nothing)
+        const bool have = lt < nlds;
+        const size_t pt = ((size_t)tile0 + wv * tpw + RT + lt) * 16 + lr;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2)
+            xb[((size_t)(wv * p.ltw + lt) * KS + s2) * 64 + lane] = have ? p.Xa[(size_t)(4 * s2 + lk) * p.Npad + pt] : 0.0;
+        if (lk == 0) al_s[(wv * p.ltw + lt) * 16 + lr] = have ? p.alpha[pt] : 0.0;
+    }
     if (tid < 256) etab[tid] = exp2((double)tid * 0.00390625);
     if (tid < 2) ctl_s[tid] = 0;
     for (int i = tid; i < NW * QPAD; i += 512) wsum[i] = 0.0;
     const int k = lane & (LPR - 1);                          // this lane's word of a row: k < d coordinate, k == d logp
     const int pl = lane >> LSH;                              // proposal slot within the wave
-    const bool seg = k >= G;                                 // which half of the slot's lanes: own row's / partner row's partials
+    const bool seg = k >= HALF;                              // which half of the slot's lanes: own row's / partner row's partials
     const int pwv = NW - 1 - wv;                             // the LAST wave takes the first proposals: wave 0 publishes the partials
     const double il_r = (k < d) ? p.consts[k] : 0.0, lo_r = (k < d) ? p.consts[ALABI_MAX_DIM + k] : 0.0;
     const double hi_r = (k < d) ? p.consts[2 * ALABI_MAX_DIM + k] : 0.0;
@@ -247,9 +271,6 @@ ens_group_kernel(GroupArgs p) {
     }
     __syncthreads();
 
-    const int tpw = (ntile + NW - 1) / NW;                   // point tiles per wave
-    const int tl_begin = wv * tpw, tl_end = (tl_begin + tpw < ntile) ? tl_begin + tpw : ntile;
-    const int lr = lane & 15, lk = lane >> 4;
 
     // per-pass constants of this lane: its proposal, is this member responsible for it, where its candidate goes
     bool mine_[NPM];
@@ -318,9 +339,9 @@ ens_group_kernel(GroupArgs p) {
                 }
                 const int my_c = seg ? cp : co, my_p = seg ? pq : po;
                 if (my_c >= 0 && (!seg || want_partner)) {
-                    pb_[ps] = p.part + my_p + (k & (G - 1));
                     pc_[ps] = p.cand + my_c + 2 * d;
-                    want |= 0x1F0u;
+                    want |= 0x1E0u;
+                    if ((k & (HALF - 1)) < G) { pb_[ps] = p.part + my_p + (k & (HALF - 1)); want |= 0x10u; }
                 } else if (!seg) {
                     pc_[ps] = p.hist + (size_t)w * row + d;  // version 0: the logp of hist row 0
                     want |= 0x20u;
@@ -395,11 +416,11 @@ ens_group_kernel(GroupArgs p) {
             if (ps * PPP + pwv * PPW >= cnt) continue;       // wave-uniform
             const int pp = ps * PPP + pwv * PPW + pl;
             // accept test of the proposal that produced this half's row, in every lane of the half
-            const double sm = seg_allsum<G>(grp_dbl(vb_[ps]));
+            const double sm = seg_allsum<G, HALF>(grp_dbl(vb_[ps]));
             const double lp_old = grp_dbl(vc_[ps][0]);
             int accf = 0;
             double lp_sel = lp_old;
-            if (want_[ps] & 16u) {
+            if (want_[ps] & 0x40u) {                          // this half's row has a producing proposal inside the launch
                 const double lp_new = fma(p.amp, sm, p.mean) + grp_dbl(vc_[ps][3]);
                 accf = (grp_dbl(vc_[ps][1]) + lp_new - lp_old > grp_dbl(vc_[ps][2])) ? 1 : 0;
                 lp_sel = accf ? lp_new : lp_old;
@@ -506,23 +527,28 @@ ens_group_kernel(GroupArgs p) {
         v4f64 sum[Q];
 #pragma unroll
         for (int qt = 0; qt < Q; ++qt) sum[qt] = v4f64{0.0, 0.0, 0.0, 0.0};
-        for (int tl = tl_begin; tl < tl_end; ++tl) {
-            const double* xbt = xb + (size_t)tl * KS * 64 + lane;
-            double bop[KS];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) bop[s] = xbt[s * 64];
-            const double al = al_s[tl * 16 + lr];
+        auto tile_products = [&](const double* bop, double al) {
 #pragma unroll
             for (int qt = 0; qt < Q; ++qt) {
                 v4f64 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qt][s], bop[s], acc, 0, 0, 0);
+                for (int s2 = 0; s2 < KS; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qt][s2], bop[s2], acc, 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {                // C/D layout: row (proposal) lk + 4 i, column (point) lr
                     const double f = GENERIC ? radial<true>(fmax(-2.0 * acc[i], 0.0), p.kf) : exp2s_tab256(acc[i], etab);
                     sum[qt][i] = fma(al, f, sum[qt][i]);
                 }
             }
+        };
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            if (r < nreg) tile_products(xr[r], ar[r]);       // wave-uniform
+        for (int lt = 0; lt < nlds; ++lt) {
+            const double* xbt = xb + (size_t)(wv * p.ltw + lt) * KS * 64 + lane;
+            double bop[KS];
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) bop[s2] = xbt[s2 * 64];
+            tile_products(bop, al_s[(wv * p.ltw + lt) * 16 + lr]);
         }
 #pragma unroll
         for (int qt = 0; qt < Q; ++qt)
@@ -571,9 +597,10 @@ ens_group_kernel(GroupArgs p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Host side: the blocking for an ensemble, buffers, launch.
 struct GroupPlan {
-    int ok, KS, Q, QP, G, NG, S;
+    int ok, KS, Q, QP, G, NG, RT, tpm, ltw;
     size_t lds_bytes;
 };
+#define ALABI_GRP_RT 5                           // point tiles per wave held in registers by the G8 instantiations
 
 static int group_n_cu() {
     static int n_cu = 0;
@@ -585,30 +612,41 @@ static int group_n_cu() {
     return n_cu;
 }
 
-// G = 8 members per group for d <= 14 (rows of <= 16 words), 16 beyond; as many groups as the CUs allow, each with the
-// smallest power-of-two number Q of 16-proposal tiles that covers its share of a half step.
+// G members per group: 8 for d <= 14 (rows of <= 16 words); for wider rows 8 with four point tiles per wave in registers when the
+// rest of the slice then fits LDS, else 16; as many groups as the CUs allow, each with the smallest power-of-two number Q of
+// 16-proposal tiles that covers its share of a half step.
 static GroupPlan group_plan(const alabi_ens* e) {
-    GroupPlan pl{};
     const alabi_gp* gp = e->gp;
     const int d = e->d;
-    if (d + 2 > 32 || e->ymap != 0 || e->W < 2) return pl;
+    GroupPlan none{};
+    if (d + 2 > 32 || e->ymap != 0 || e->W < 2) return none;
     const int n_cu = group_n_cu();
-    if (e->E > n_cu) return pl;
+    if (e->E > n_cu) return none;
     const int KS = (d + 2 + 3) / 4;
-    const int G = (KS <= 4) ? 8 : 16;
-    const int ng_max = n_cu / e->E / G;
-    if (ng_max < 1) return pl;
     const int n0 = (e->W + 1) / 2;
-    int Q = 1;
-    while (Q < 8 && (n0 + 16 * Q - 1) / (16 * Q) > ng_max) Q *= 2;
-    if ((n0 + 16 * Q - 1) / (16 * Q) > ng_max) return pl;
-    if (KS > 4 && Q > 4) return pl;                          // passes of the row phase: 16 Q proposals / (8 waves x 2) <= 4
     const int tiles = gp->Npad / 16;
-    pl.KS = KS; pl.Q = Q; pl.QP = 16 * Q; pl.G = G; pl.NG = (n0 + pl.QP - 1) / pl.QP;
-    pl.S = ((tiles + G - 1) / G) * 16;
-    pl.lds_bytes = (size_t)group_lds(KS, pl.QP, pl.S).total * 8;
-    pl.ok = pl.lds_bytes <= 160 * 1024 - 512;
-    return pl;
+    const char* g16 = getenv("ALABI_ENS_GROUP_G16");          // tests: the 16-member blocking where 8 members would be chosen
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        GroupPlan pl{};
+        const bool wide = KS > 4;
+        if (attempt == 0 && (!wide || (g16 && g16[0] == '1'))) continue;    // attempt 0: eight members for wide rows
+        const int G = (wide && attempt == 1) ? 16 : 8;
+        const int RT = (wide && attempt == 0) ? ALABI_GRP_RT : 0;
+        const int ng_max = n_cu / e->E / G;
+        if (ng_max < 1) continue;
+        int Q = 1;
+        while (Q < 8 && (n0 + 16 * Q - 1) / (16 * Q) > ng_max) Q *= 2;
+        if ((n0 + 16 * Q - 1) / (16 * Q) > ng_max) continue;
+        if (wide && Q > 4) continue;                         // passes of the row phase: 16 Q proposals / (8 waves x 2) <= 4
+        pl.KS = KS; pl.Q = Q; pl.QP = 16 * Q; pl.G = G; pl.NG = (n0 + pl.QP - 1) / pl.QP; pl.RT = RT;
+        pl.tpm = (tiles + G - 1) / G;
+        const int tpw = (pl.tpm + ALABI_GRP_NW - 1) / ALABI_GRP_NW;
+        pl.ltw = tpw > RT ? tpw - RT : 0;
+        pl.lds_bytes = (size_t)group_lds(KS, pl.QP, ALABI_GRP_NW * pl.ltw).total * 8;
+        pl.ok = pl.lds_bytes <= 160 * 1024 - 512;
+        if (pl.ok) return pl;
+    }
+    return none;
 }
 
 bool ens_group_fits(const alabi_ens* e) { return e->hist && e->err && group_plan(e).ok; }
@@ -644,14 +682,17 @@ static int group_launch(const GroupArgs& a, const GroupPlan& pl, int E, hipStrea
     if constexpr (KS > 4 && Q > 4) {
         return ALABI_BAD_ARGUMENT;
     } else {
-        auto kern = ens_group_kernel<KS, Q, GENERIC>;
-        static bool attr_set = false;                        // per instantiation
-        if (!attr_set) {
-            ALABI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+        const void* kern = (pl.G == 8 && KS > 4) ? reinterpret_cast<const void*>(ens_group_kernel<KS, Q, (KS > 4), (KS > 4 ? ALABI_GRP_RT : 0), GENERIC>)
+                                                 : reinterpret_cast<const void*>(ens_group_kernel<KS, Q, false, 0, GENERIC>);
+        static bool attr_set[2] = {false, false};            // per instantiation of this function, per variant
+        const int var = (pl.G == 8 && KS > 4) ? 1 : 0;
+        if (!attr_set[var]) {
+            ALABI_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[var] = true;
         }
-        hipLaunchKernelGGL(kern, dim3(pl.NG * pl.G, E), dim3(512), pl.lds_bytes, s, a);
-        ALABI_LAUNCH_CHECK();
+        GroupArgs args = a;
+        void* params[] = {&args};
+        ALABI_HIP_CHECK(hipLaunchKernel(kern, dim3(pl.NG * pl.G, E), dim3(512), params, pl.lds_bytes, s));
         return ALABI_OK;
     }
 }
@@ -686,7 +727,7 @@ int launch_ens_group(alabi_ens* e, double* coords, double* logp, int K, int thin
     a.consts = e->consts;
     a.Xa = gp->Xa; a.centre = gp->xa_centre; a.alpha = gp->alpha;
     a.K = K; a.W = e->W; a.n0 = n0; a.d = e->d; a.Npad = gp->Npad;
-    a.NG = pl.NG; a.QP = pl.QP; a.S = pl.S;
+    a.NG = pl.NG; a.QP = pl.QP; a.tpm = pl.tpm; a.ltw = pl.ltw;
     a.xcd_map = 1;                                           // measured at C4: 6.23 us per half step with it, 6.58 without (first version)
     a.spin_limit = 1 << 20;
     if (const char* env = getenv("ALABI_ENS_SPIN_LIMIT")) { const int v = atoi(env); if (v > 0) a.spin_limit = v - 1; }   // tests: force a time-out (1: the first miss)
