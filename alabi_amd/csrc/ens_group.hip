@@ -629,15 +629,16 @@ static GroupPlan group_plan(const alabi_ens* e) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         GroupPlan pl{};
         const bool wide = KS > 4;
-        if (attempt == 0 && (!wide || (g16 && g16[0] == '1'))) continue;    // attempt 0: eight members for wide rows
+        if (attempt == 0 && g16 && g16[0] == '1') continue;  // attempt 0: the instantiation with register-resident point tiles
         const int G = (wide && attempt == 1) ? 16 : 8;
-        const int RT = (wide && attempt == 0) ? ALABI_GRP_RT : 0;
+        const int RT = (attempt == 0) ? ALABI_GRP_RT : 0;
         const int ng_max = n_cu / e->E / G;
         if (ng_max < 1) continue;
         int Q = 1;
         while (Q < 8 && (n0 + 16 * Q - 1) / (16 * Q) > ng_max) Q *= 2;
         if ((n0 + 16 * Q - 1) / (16 * Q) > ng_max) continue;
         if (wide && Q > 4) continue;                         // passes of the row phase: 16 Q proposals / (8 waves x 2) <= 4
+        if (!wide && RT > 0 && Q > 2) continue;              // (register budget of the narrow-row instantiations with many proposal tiles)
         pl.KS = KS; pl.Q = Q; pl.QP = 16 * Q; pl.G = G; pl.NG = (n0 + pl.QP - 1) / pl.QP; pl.RT = RT;
         pl.tpm = (tiles + G - 1) / G;
         const int tpw = (pl.tpm + ALABI_GRP_NW - 1) / ALABI_GRP_NW;
@@ -682,10 +683,11 @@ static int group_launch(const GroupArgs& a, const GroupPlan& pl, int E, hipStrea
     if constexpr (KS > 4 && Q > 4) {
         return ALABI_BAD_ARGUMENT;
     } else {
-        const void* kern = (pl.G == 8 && KS > 4) ? reinterpret_cast<const void*>(ens_group_kernel<KS, Q, (KS > 4), (KS > 4 ? ALABI_GRP_RT : 0), GENERIC>)
+        constexpr bool HAS_RT = (KS > 4) || (Q <= 2);        // instantiations with register-resident tiles
+        const void* kern = (pl.RT > 0 && HAS_RT) ? reinterpret_cast<const void*>(ens_group_kernel<KS, Q, (KS > 4), (HAS_RT ? ALABI_GRP_RT : 0), GENERIC>)
                                                  : reinterpret_cast<const void*>(ens_group_kernel<KS, Q, false, 0, GENERIC>);
         static bool attr_set[2] = {false, false};            // per instantiation of this function, per variant
-        const int var = (pl.G == 8 && KS > 4) ? 1 : 0;
+        const int var = (pl.RT > 0 && HAS_RT) ? 1 : 0;
         if (!attr_set[var]) {
             ALABI_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set[var] = true;

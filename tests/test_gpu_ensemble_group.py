@@ -62,6 +62,26 @@ def test_group_kernel_chain_vs_oracle(N, d, W, nsteps, monkeypatch):
     assert 0.02 < s.acceptance_fraction.mean() < 0.98
 
 
+def test_group_kernel_sixteen_member_blocking(monkeypatch):
+    """Wide rows (d = 20) normally run with eight members per group and part of each wave's point tiles in registers;
+    ALABI_ENS_GROUP_G16=1 selects the sixteen-member instantiation (what the planner falls back to when a slice does not fit):
+    same chain to rounding, same acceptance counts."""
+    from alabi_amd import EnsembleSampler
+    g, o, y = _pair(1500, 20, 120, ell2=40.0)
+    bounds = np.array([[-3.0, 3.0]] * 20)
+    p0 = np.random.RandomState(5).uniform(-2, 2, (96, 20))
+    monkeypatch.setenv("ALABI_ENS_GROUP", "1")
+    runs = []
+    for g16 in ("0", "1"):
+        monkeypatch.setenv("ALABI_ENS_GROUP_G16", g16)
+        s = EnsembleSampler(96, 20, g, y, bounds, seed=777)
+        s.run_mcmc(p0, 60)
+        assert s.last_path == "group"
+        runs.append((s.get_chain(), s._naccept.cpu().numpy().copy()))
+    assert np.max(np.abs(runs[0][0] - runs[1][0])) <= 1e-7
+    assert np.array_equal(runs[0][1], runs[1][1])
+
+
 def test_group_kernel_matches_half_step_path_and_continues(monkeypatch):
     """Two consecutive runs (the second continues the first), thinning, several ensembles per launch: the group kernel
     agrees with the launch-per-half-step kernels to rounding and the acceptance counters are identical."""
