@@ -663,7 +663,10 @@ int alabi_ens_run(alabi_ens* e, double* coords, double* logp, long long step0, l
     const char* genv = getenv("ALABI_ENS_GROUP");
     const bool group_off = genv && genv[0] == '0', group_pref = genv && genv[0] == '1';
     const bool can_stream = ens_stream_fits(e);
-    const bool use_group = e->stream_ok && s != nullptr && !group_off && (group_pref || !can_stream) && ens_group_fits(e);
+    // ens_stream_kernel takes ceil(W/2 / stream_grid) proposals per workgroup one after the other (2.0 / 3.7 / 7.1 us per half step at
+    // 1 / 2 / 4 of them, N = 2000); from four on the group kernel is ahead (5.3 us at W = 2048: 1.9e8 against 1.4e8 samples/s)
+    const bool crowded = can_stream && e->stream_grid > 0 && ((e->W + 1) / 2 + e->stream_grid - 1) / e->stream_grid >= 4;
+    const bool use_group = e->stream_ok && s != nullptr && !group_off && (group_pref || !can_stream || crowded) && ens_group_fits(e);
     if (e->stream_ok && s != nullptr && (can_stream || use_group)) {
         e->last_path = use_group ? 3 : 1;
         ALABI_HIP_CHECK(hipMemsetAsync(e->err, 0, sizeof(int), s));
