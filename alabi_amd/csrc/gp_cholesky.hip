@@ -520,21 +520,24 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
 // type & 255: 0 CHAIN(k), 1 TRSM(i,k), 2 UPDATE(i,j,k..k+cnt-1) with cnt = type >> 8 consecutive block columns (chol_build_tasks)
 struct CholTask { int type, i, j, k; };
 #define ALABI_CHOL_TASKS_MAX_NB 160   // default upper end of the one-launch task queue (N <= 10240); beyond: panels of 8 block columns
+#define ALABI_CHOL_W8_MIN_NB 40   // block columns from which the queue runs eight waves per workgroup (chol_tasks8_kernel)
 #define ALABI_CHOL_PLAIN_MIN 4   // block columns per UPDATE from which its operands are read with ordinary loads behind one acquire
 
 
+template <int NT>
 __device__ inline void tile_load_sc1(double (*T)[66], const double* __restrict__ src, int ld, int tid) {
 #pragma unroll
-    for (int e_ = 0; e_ < 16; ++e_) {
-        const int e = tid + 256 * e_, r = e >> 6, c = e & 63;
+    for (int e_ = 0; e_ < 4096 / NT; ++e_) {
+        const int e = tid + NT * e_, r = e >> 6, c = e & 63;
         T[r][c] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(src + (size_t)r * ld + c),
                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
 }
+template <int NT>
 __device__ inline void tile_store_sc1(double* __restrict__ dst, int ld, double (*T)[66], int tid, bool lower_only) {
 #pragma unroll
-    for (int e_ = 0; e_ < 16; ++e_) {
-        const int e = tid + 256 * e_, r = e >> 6, c = e & 63;
+    for (int e_ = 0; e_ < 4096 / NT; ++e_) {
+        const int e = tid + NT * e_, r = e >> 6, c = e & 63;
         if (!lower_only || c <= r)
             __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + (size_t)r * ld + c),
                                (unsigned long long)__double_as_longlong(T[r][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -545,21 +548,6 @@ __device__ inline void publish_version(int* ver, int value, int tid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(ver, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// X L_kk^T = B for the 64 rows of `bs` (in place), L_kk in `lkk`, 1 / L_jj in `di`: the body of trsm_panel_kernel.
-__device__ inline void trsm_tile_lds(double (*lkk)[66], double (*bs)[66], const double* di, int tid) {
-    const int w = tid >> 6, lane = tid & 63;
-    const int row = 16 * w + (lane & 15);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int c0 = 16 * s;
-        if (lane < 16) trsm_slab_row<66>(lkk, bs, di, row, c0);
-        __syncthreads();
-#pragma unroll
-        for (int t = s + 1; t < 4; ++t) tile_update_16<66>(bs, 16 * w, 16 * t, bs, 16 * w, lkk, 16 * t, c0, lane);
-        __syncthreads();
-    }
 }
 
 // Module-scope LDS, named directly by the non-inlined phase functions (as pointer arguments they would degrade to generic
@@ -581,6 +569,7 @@ __device__ __attribute__((noinline)) void ct_trsm_rec() {
 template <int S>
 __device__ __attribute__((noinline)) void ct_trsm_upd() {
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    if (w >= 4) return;                                        // the helper waves of the 8-wave kernel own no rows here
 #pragma unroll
     for (int t = S + 1; t < 4; ++t) tile_update_16<66>(ct_T1, 16 * w, 16 * t, ct_T1, 16 * w, ct_T0, 16 * t, 16 * S, lane);
 }
@@ -637,21 +626,27 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
     if (bad != 0 && lane == 0) atomicCAS(info, 0, kb * 64 + bad);
     return potrf_dinv(lll);
 }
+// One ds_read_b64 that the compiler will not pair with a neighbour into a ds_read2_b64 (volatile, LDS address space)
+__device__ inline double lds_read_b64(const double* p) {
+    return *(const volatile __attribute__((address_space(3))) double*)p;
+}
 // A tile in flight: all 16 loads of a thread are issued before the first one is consumed (several tiles are fetched
 // back to back and only then written to LDS: one memory round trip instead of one per tile)
-struct TileRegs { unsigned long long v[16]; };
-__device__ inline void tile_fetch(TileRegs& r, const double* __restrict__ src, int ld, int tid) {
+template <int NT> struct TileRegs { unsigned long long v[4096 / NT]; };
+template <int NT>
+__device__ inline void tile_fetch(TileRegs<NT>& r, const double* __restrict__ src, int ld, int tid) {
 #pragma unroll
-    for (int e_ = 0; e_ < 16; ++e_) {
-        const int e = tid + 256 * e_;
+    for (int e_ = 0; e_ < 4096 / NT; ++e_) {
+        const int e = tid + NT * e_;
         r.v[e_] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src + (size_t)(e >> 6) * ld + (e & 63)), __ATOMIC_RELAXED,
                                     __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-__device__ inline void tile_put(double (*T)[66], const TileRegs& r, int tid) {
+template <int NT>
+__device__ inline void tile_put(double (*T)[66], const TileRegs<NT>& r, int tid) {
 #pragma unroll
-    for (int e_ = 0; e_ < 16; ++e_) {
-        const int e = tid + 256 * e_;
+    for (int e_ = 0; e_ < 4096 / NT; ++e_) {
+        const int e = tid + NT * e_;
         T[e >> 6][e & 63] = __longlong_as_double((long long)r.v[e_]);
     }
 }
@@ -659,32 +654,52 @@ __device__ inline void tile_put(double (*T)[66], const TileRegs& r, int tid) {
 // The same through 16-byte write-through-coherent (sc1) buffer loads: half the load instructions and twice the bytes per request
 // (8-byte sc1 accesses run at 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md) -- the operand stream of the bulk updates.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-struct TileRegs16 { u32x4 v[8]; };
+template <int NT> struct TileRegs16 { u32x4 v[2048 / NT]; };
 // PLAIN: ordinary (L2-cached) loads -- valid behind an agent-scope acquire of the hand-off that published the tile (Guideline 16)
-template <bool PLAIN>
-__device__ inline void tile_fetch16(TileRegs16& r, __amdgpu_buffer_rsrc_t rs, unsigned tile_bytes, int ld, int tid) {
+template <bool PLAIN, int NT>
+__device__ inline void tile_fetch16(TileRegs16<NT>& r, __amdgpu_buffer_rsrc_t rs, unsigned tile_bytes, int ld, int tid) {
 #pragma unroll
-    for (int e_ = 0; e_ < 8; ++e_) {
-        const int e = tid + 256 * e_;
+    for (int e_ = 0; e_ < 2048 / NT; ++e_) {
+        const int e = tid + NT * e_;
         r.v[e_] = __builtin_amdgcn_raw_buffer_load_b128(rs, tile_bytes + (unsigned)(((e >> 5) * ld + 2 * (e & 31)) * 8), 0, PLAIN ? 0 : 16);
     }
 }
-__device__ inline void tile_put16(double (*T)[66], const TileRegs16& r, int tid) {
+// element e_ of a tile's registers alone: the grouped updates spread the fetch and the LDS write of the next operands over the
+// k-steps of the current block column (one of each per k-step pair) instead of issuing them as a burst around the barrier
+template <bool PLAIN, int NT>
+__device__ inline void tile_fetch16_one(TileRegs16<NT>& r, int e_, __amdgpu_buffer_rsrc_t rs, unsigned tile_bytes, int ld, int tid) {
+    const int e = tid + NT * e_;
+    r.v[e_] = __builtin_amdgcn_raw_buffer_load_b128(rs, tile_bytes + (unsigned)(((e >> 5) * ld + 2 * (e & 31)) * 8), 0, PLAIN ? 0 : 16);
+}
+template <int NT>
+__device__ inline void tile_put16_one(double (*T)[66], const TileRegs16<NT>& r, int e_, int tid) {
+    const int e = tid + NT * e_;
+    *reinterpret_cast<u32x4*>(&T[e >> 5][2 * (e & 31)]) = r.v[e_];
+}
+template <int NT>
+__device__ inline void tile_put16(double (*T)[66], const TileRegs16<NT>& r, int tid) {
 #pragma unroll
-    for (int e_ = 0; e_ < 8; ++e_) {
-        const int e = tid + 256 * e_;
+    for (int e_ = 0; e_ < 2048 / NT; ++e_) {
+        const int e = tid + NT * e_;
         *reinterpret_cast<u32x4*>(&T[e >> 5][2 * (e & 31)]) = r.v[e_];
     }
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __restrict__ tasks, int ntasks, int* __restrict__ ctl,
-                  int* __restrict__ info, double* __restrict__ dinv, int spin_limit) {
+// NT = 256: four waves, one per SIMD, up to 512 registers per lane (the shape the chain-bound sizes were tuned on).
+// NT = 512 (round 3, many block columns): four HELPER waves join for the UPDATE tasks -- two matrix-core waves per SIMD (66-70
+// instead of 56-59 TFLOP/s of v_mfma_f64_16x16x4, tools/micro/mfma_f64_rate), wave w owning rows 16 (w & 3).., columns
+// 32 (w >> 2).. of the tile -- and for every tile load / store; in the serial parts of CHAIN and TRSM tasks they only keep the
+// barriers company, so the chain runs as fast as with four waves (two workgroups of four waves per CU were measured instead:
+// the grouped updates gained 27 %, but every recurrence that shared its SIMD with the other workgroup's matrix-core
+// instructions took 1.5-1.8x as long and the singles waited five times longer for their inputs; N = 10000 9.86 -> 9.59 ms only).
+template <int NT>
+__device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, int nb, const CholTask* __restrict__ tasks, int ntasks,
+                                                int* __restrict__ ctl, int* __restrict__ info, double* __restrict__ dinv, int spin_limit) {
     double (*T0)[66] = ct_T0; double (*T1)[66] = ct_T1; double (*T2)[66] = ct_T2; double (*T3)[66] = ct_T3; double* di = ct_di;
     __shared__ int task_s[6];
     int* head = ctl; int* err = ctl + 1; int* ver = ctl + 2;          // ver[i * nb + j]
     int* sver = ctl + 2 + nb * nb;                                    // sver[k]: slabs of L[k,k] published so far (0..4)
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+    int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(A, 0, (unsigned)ld * (unsigned)ld * 8u, 0x00020000);
     // Panel solve of the tile in T1 against L[kk,kk], consumed slab by slab as its factorisation publishes them (sver[kk] =
     // slabs written through so far): wait (bounded), fetch the slab's 64 x 16 block and its reciprocals, solve the slab,
@@ -706,18 +721,18 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
         __syncthreads();
         if (task_s[4] >= ntasks) return false;
         {
-            unsigned long long v[4];
+            unsigned long long v[1024 / NT];
 #pragma unroll
-            for (int e_ = 0; e_ < 4; ++e_) {
-                const int e = tid + 256 * e_;
+            for (int e_ = 0; e_ < 1024 / NT; ++e_) {
+                const int e = tid + NT * e_;
                 v[e_] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(Lp + (size_t)(e >> 4) * ld + (e & 15)), __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_AGENT);
             }
             if (tid < 16) di[tid] = __longlong_as_double((long long)__hip_atomic_load(
                               reinterpret_cast<const unsigned long long*>(dinv + kk * 64 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
-            for (int e_ = 0; e_ < 4; ++e_) {
-                const int e = tid + 256 * e_;
+            for (int e_ = 0; e_ < 1024 / NT; ++e_) {
+                const int e = tid + NT * e_;
                 T0[e >> 4][e & 15] = __longlong_as_double((long long)v[e_]);
             }
         }
@@ -760,7 +775,7 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
                         T0[e >> 4][16 * (sl + 1) + (e & 15)] = __longlong_as_double((long long)v[e_]);
                     }
                 }
-            } else if (w >= 2 && sl >= 1) {
+            } else if ((w == 2 || w == 3) && sl >= 1) {
                 side(sl - 1);
             }
             __syncthreads();                                          // the slab is solved, the next one is in LDS
@@ -773,6 +788,12 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
         return true;
     };
     for (;;) {
+        if (NT == 512) {
+            // 256 registers per lane: the per-thread tile offsets of every task type must not be hoisted out of the task loop (the
+            // compiler then keeps ~115 loop-invariant addresses and spills them) -- they are re-derived per task from an opaque tid
+            asm volatile("" : "+v"(tid));
+            w = tid >> 6; l = tid & 63; lr = l & 15; lk = l >> 4;
+        }
         __syncthreads();                                              // the previous task is done with LDS and task_s
         if (tid == 0) {
             const int idx = atomicAdd(head, 1);
@@ -841,48 +862,100 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
 #endif
             auto update_range = [&](auto plain_tag) {
                 constexpr bool PL = decltype(plain_tag)::value;
-                TileRegs16 ra, rb;
+                constexpr int NN = NT == 512 ? 2 : 4;                  // 16 x 16 tiles per wave: 16 rows x (64 or 32) columns
+                const int wr = w & 3, c0w = NT == 512 ? 32 * (w >> 2) : 0;
+                TileRegs16<NT> ra, rb;
                 const unsigned row_i = (unsigned)(ti * 64) * (unsigned)ld * 8u, row_j = (unsigned)(tj * 64) * (unsigned)ld * 8u;
-                tile_fetch16<PL>(ra, arsrc, row_i + (unsigned)tk * 512u, ld, tid);
-                tile_fetch16<PL>(rb, arsrc, row_j + (unsigned)tk * 512u, ld, tid);
-                double* C = A + (size_t)(ti * 64 + 16 * w) * ld + tj * 64;
-                v4f64 acc[4];
+                tile_fetch16<PL, NT>(ra, arsrc, row_i + (unsigned)tk * 512u, ld, tid);
+                tile_fetch16<PL, NT>(rb, arsrc, row_j + (unsigned)tk * 512u, ld, tid);
+                double* C = A + (size_t)(ti * 64 + 16 * wr) * ld + tj * 64 + c0w;
+                v4f64 acc[NN];
     #pragma unroll
-                for (int n = 0; n < 4; ++n)
+                for (int n = 0; n < NN; ++n)
     #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         acc[n][i] = __longlong_as_double((long long)__hip_atomic_load(
                             reinterpret_cast<const unsigned long long*>(C + (size_t)(lk + 4 * i) * ld + 16 * n + lr), __ATOMIC_RELAXED,
                             __HIP_MEMORY_SCOPE_AGENT));
-                tile_put16(T0, ra, tid); tile_put16(T1, rb, tid);
-                // every load so far has landed before the loop starts: otherwise the compiler's wait for the C tile sits INSIDE the loop
-                // (vmcnt is one in-order counter) and drains the operand prefetch of every iteration
-                __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+                tile_put16<NT>(T0, ra, tid); tile_put16<NT>(T1, rb, tid);
+                // Column k' + 1 waits in LDS and column k' + 2 is in flight while the matrix cores work on column k': the registers of
+                // a fetch are written to the other operand pair at the START of the next iteration (its last readers passed the
+                // barrier before) and refilled at once, so no wave waits for memory or for the LDS writes between two columns.
+                // The C tile has landed before the loop starts: otherwise the compiler's wait for it sits INSIDE the loop (vmcnt is one
+                // in-order counter) and drains the operand prefetch of every iteration.
+                if (tcnt > 1) {
+                    tile_fetch16<PL, NT>(ra, arsrc, row_i + (unsigned)(tk + 1) * 512u, ld, tid);
+                    tile_fetch16<PL, NT>(rb, arsrc, row_j + (unsigned)(tk + 1) * 512u, ld, tid);
+                }
+    #pragma unroll
+                for (int n = 0; n < NN; ++n) asm volatile("" : "+v"(acc[n]));   // C is waited for HERE (the fetch above stays in flight)
                 __syncthreads();
 #ifdef ALABI_CHOL_PROF
                 u1 = __builtin_amdgcn_s_memrealtime();
 #endif
-                for (int c = 0; c < tcnt; ++c) {
-                    const bool more = c + 1 < tcnt;
-                    if (more) {
-                        tile_fetch16<PL>(ra, arsrc, row_i + (unsigned)(tk + c + 1) * 512u, ld, tid);
-                        tile_fetch16<PL>(rb, arsrc, row_j + (unsigned)(tk + c + 1) * 512u, ld, tid);
-                    }
+                // One block column: MORE = column c + 1 exists (its pieces go registers -> the other LDS pair), MORE2 = column c + 2 exists
+                // (memory -> the same registers).  Compile-time flags, so that a column is straight-line code and the compiler can count
+                // vmcnt exactly: behind a branch it waits for vmcnt(0) in front of every piece, i.e. for the load issued one k-step pair ago.
+                auto column = [&](auto more_tag, auto more2_tag, int c) {
+                    constexpr bool MORE = decltype(more_tag)::value, MORE2 = decltype(more2_tag)::value;
+                    const unsigned col2 = (unsigned)(tk + c + 2) * 512u;
+                    double (*Pa)[66] = (c & 1) ? T0 : T2;                 // the other pair: block column c + 1 goes there
+                    double (*Pb)[66] = (c & 1) ? T1 : T3;
                     double (*Ta)[66] = (c & 1) ? T2 : T0;
                     double (*Tb)[66] = (c & 1) ? T3 : T1;
+                    // software pipeline over pairs of k-steps: the LDS reads of pair kp + 1 are issued before the matrix-core instructions
+                    // of pair kp (two register sets; sched_barrier keeps the compiler from sinking the reads next to their uses --
+                    // it otherwise reads, waits, multiplies, and every pair of k-steps exposes one LDS round trip)
+                    double pa[2][2], pb[2][2][NN];
+                    auto lds_pair = [&](int set, int kp) {
     #pragma unroll
-                    for (int ks = 0; ks < 16; ++ks) {
-                        const double a = -Ta[16 * w + lr][4 * ks + lk];
+                        for (int h = 0; h < 2; ++h) {
+                            // volatile: ONE ds_read_b64 per operand (conflict-free with the row stride of 66: 2 LDS cycles).  Left to
+                            // itself the compiler pairs them into ds_read2_b64, which is banked modulo 32 and serviced in groups of 16
+                            // lanes: rows r and r + 8 collide, 16 LDS cycles per instruction -- the LDS then co-limits the loop
+                            pa[set][h] = lds_read_b64(&Ta[16 * wr + lr][4 * (2 * kp + h) + lk]);
     #pragma unroll
-                        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Tb[16 * n + lr][4 * ks + lk], acc[n], 0, 0, 0);
+                            for (int n = 0; n < NN; ++n)
+                                pb[set][h][n] = lds_read_b64(&Tb[c0w + 16 * n + lr][4 * (2 * kp + h) + lk]);
+                        }
+                    };
+                    lds_pair(0, 0);
+    #pragma unroll
+                    for (int kp = 0; kp < 8; ++kp) {
+                        if (kp < 7) lds_pair((kp + 1) & 1, kp + 1);
+                        // one piece of block column c + 1 and of column c + 2 per k-step pair (NE pieces per operand tile, 2 NE / 8 per
+                        // pair) instead of a burst of LDS writes and loads around the barrier, when no wave has matrix-core work
+                        {
+                            constexpr int NE = 2048 / NT, PER = 2 * NE / 8;
+    #pragma unroll
+                            for (int q = PER * kp; q < PER * (kp + 1); ++q) {
+                                if (q < NE) {
+                                    if (MORE) tile_put16_one<NT>(Pa, ra, q, tid);
+                                    if (MORE2) tile_fetch16_one<PL, NT>(ra, q, arsrc, row_i + col2, ld, tid);
+                                } else {
+                                    if (MORE) tile_put16_one<NT>(Pb, rb, q - NE, tid);
+                                    if (MORE2) tile_fetch16_one<PL, NT>(rb, q - NE, arsrc, row_j + col2, ld, tid);
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                        for (int h = 0; h < 2; ++h)
+    #pragma unroll
+                            for (int n = 0; n < NN; ++n)
+                                acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[kp & 1][h], pb[kp & 1][h][n], acc[n], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (more) {                                           // the other pair was last read one iteration ago: every wave is past that barrier
-                        tile_put16((c & 1) ? T0 : T2, ra, tid); tile_put16((c & 1) ? T1 : T3, rb, tid);
-                        __syncthreads();
-                    }
+                };
+                for (int c = 0; c < tcnt; ++c) {
+                    const bool more = c + 1 < tcnt;
+                    if (c + 2 < tcnt) column(std::true_type{}, std::true_type{}, c);
+                    else if (more) column(std::true_type{}, std::false_type{}, c);
+                    else column(std::false_type{}, std::false_type{}, c);
+                    if (more) __syncthreads();                            // pair (c + 1) is complete, pair c may be overwritten
                 }
     #pragma unroll
-                for (int n = 0; n < 4; ++n)
+                for (int n = 0; n < NN; ++n)
     #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         __hip_atomic_store(reinterpret_cast<unsigned long long*>(C + (size_t)(lk + 4 * i) * ld + 16 * n + lr),
@@ -905,12 +978,12 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
         } else if (type == 1) {
             // ---------------- TRSM(i, k)
             {
-                TileRegs rb;
-                tile_fetch(rb, A + (size_t)(ti * 64) * ld + tk * 64, ld, tid);
-                tile_put(T1, rb, tid);
+                TileRegs<NT> rb;
+                tile_fetch<NT>(rb, A + (size_t)(ti * 64) * ld + tk * 64, ld, tid);
+                tile_put<NT>(T1, rb, tid);
             }
             if (!solve_by_slabs(tk, [](int) {})) return;
-            tile_store_sc1(A + (size_t)(ti * 64) * ld + tk * 64, ld, T1, tid, false);
+            tile_store_sc1<NT>(A + (size_t)(ti * 64) * ld + tk * 64, ld, T1, tid, false);
             publish_version(ver + ti * nb + tk, tk + 1, tid);
         } else {
             // ---------------- CHAIN(k)
@@ -922,10 +995,10 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
 #endif
             if (tk > 0) {
                 {
-                    TileRegs rb, rc;
-                    tile_fetch(rb, A + (size_t)(tk * 64) * ld + (tk - 1) * 64, ld, tid);
-                    tile_fetch(rc, D, ld, tid);
-                    tile_put(T1, rb, tid); tile_put(T2, rc, tid);
+                    TileRegs<NT> rb, rc;
+                    tile_fetch<NT>(rb, A + (size_t)(tk * 64) * ld + (tk - 1) * 64, ld, tid);
+                    tile_fetch<NT>(rc, D, ld, tid);
+                    tile_put<NT>(T1, rb, tid); tile_put<NT>(T2, rc, tid);
                 }
 #ifdef ALABI_CHOL_PROF
                 p1 = __builtin_amdgcn_s_memrealtime();
@@ -962,13 +1035,13 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
 #ifdef ALABI_CHOL_PROF
                 p2 = __builtin_amdgcn_s_memrealtime();
 #endif
-                tile_store_sc1(A + (size_t)(tk * 64) * ld + (tk - 1) * 64, ld, T1, tid, false);
-                if (w >= 2) diag_update(3);                              // while the stores drain
+                tile_store_sc1<NT>(A + (size_t)(tk * 64) * ld + (tk - 1) * 64, ld, T1, tid, false);
+                if (w == 2 || w == 3) diag_update(3);                              // while the stores drain
                 publish_version(ver + tk * nb + (tk - 1), tk, tid);      // the solved panel tile is final: updates of column k can start
 #ifdef ALABI_CHOL_PROF
                 p3 = __builtin_amdgcn_s_memrealtime();
 #endif
-                if (w >= 2) {                                            // (the barrier inside publish_version: everyone is done with T0)
+                if (w == 2 || w == 3) {                                  // (the barrier inside publish_version: everyone is done with T0)
 #pragma unroll
                     for (int j = 0; j < 5; ++j) {
                         int rt, ct; dtile(j, rt, ct);
@@ -977,7 +1050,7 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
                     }
                 }
             } else {
-                tile_load_sc1(T0, D, ld, tid);
+                tile_load_sc1<NT>(T0, D, ld, tid);
             }
             __syncthreads();
 #ifdef ALABI_CHOL_PROF
@@ -989,7 +1062,7 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
 #endif
             if (w == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dinv + tk * 64 + l),
                                            (unsigned long long)__double_as_longlong(rinv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tile_store_sc1(D, ld, T0, tid, true);
+            tile_store_sc1<NT>(D, ld, T0, tid, true);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
@@ -1004,6 +1077,17 @@ chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __rest
 #endif
         }
     }
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __restrict__ tasks, int ntasks, int* __restrict__ ctl,
+                  int* __restrict__ info, double* __restrict__ dinv, int spin_limit) {
+    chol_tasks_body<256>(A, ld, nb, tasks, ntasks, ctl, info, dinv, spin_limit);
+}
+__global__ void __launch_bounds__(512)
+chol_tasks8_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __restrict__ tasks, int ntasks, int* __restrict__ ctl,
+                   int* __restrict__ info, double* __restrict__ dinv, int spin_limit) {
+    chol_tasks_body<512>(A, ld, nb, tasks, ntasks, ctl, info, dinv, spin_limit);
 }
 
 static int tiles_in_cols(int ntr, int tc0, int tc1) {
@@ -1128,7 +1212,11 @@ int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
     int grid = ntasks < n_cu ? ntasks : n_cu;
     int spin = 1 << 18;
     if (const char* e2 = getenv("ALABI_CHOL_SPIN_LIMIT")) { const int v = atoi(e2); if (v > 0) spin = v; }
-    hipLaunchKernelGGL(chol_tasks_kernel, dim3(grid), dim3(256), 0, s, gp->L, ld, nb, tasks, ntasks, gp->chol_ctl, gp->info, gp->dinv, spin);
+    // eight waves per workgroup from ALABI_CHOL_W8_MIN_NB block columns on (ALABI_CHOL_W8=0 / 1 forces four / eight)
+    bool w8 = nb >= ALABI_CHOL_W8_MIN_NB;
+    if (const char* e3 = getenv("ALABI_CHOL_W8")) w8 = e3[0] == '1';
+    if (w8) hipLaunchKernelGGL(chol_tasks8_kernel, dim3(grid), dim3(512), 0, s, gp->L, ld, nb, tasks, ntasks, gp->chol_ctl, gp->info, gp->dinv, spin);
+    else hipLaunchKernelGGL(chol_tasks_kernel, dim3(grid), dim3(256), 0, s, gp->L, ld, nb, tasks, ntasks, gp->chol_ctl, gp->info, gp->dinv, spin);
     ALABI_LAUNCH_CHECK();
 #ifdef ALABI_CHOL_PROF
     {
