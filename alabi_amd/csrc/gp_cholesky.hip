@@ -499,7 +499,7 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Task-queue factorisation for up to 128 block columns (default for N = 961..5376): ONE launch instead of 2 nb - 1.
+// Task-queue factorisation for up to 256 block columns (default for N = 961..16384): ONE launch instead of 2 nb - 1.
 // The launch-per-step path above is a chain of dependent kernels: per block column a panel solve (11 us) and an update with
 // the next diagonal factorisation fused in (19.6 us), each behind a kernel boundary -- 1.02 ms at N = 2000 for 2.67 GFLOP.
 // Here the same 64 x 64 tile operations are TASKS in a static topological order; persistent workgroups draw the next task
@@ -519,7 +519,7 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
 // j + 1 means final.
 // type & 255: 0 CHAIN(k), 1 TRSM(i,k), 2 UPDATE(i,j,k..k+cnt-1) with cnt = type >> 8 consecutive block columns (chol_build_tasks)
 struct CholTask { int type, i, j, k; };
-#define ALABI_CHOL_TASKS_MAX_NB 160   // default upper end of the one-launch task queue (N <= 10240); beyond: panels of 8 block columns
+#define ALABI_CHOL_TASKS_MAX_NB 256   // default upper end of the one-launch task queue (N <= 16384); beyond: panels of 8 block columns
 #define ALABI_CHOL_W8_MIN_NB 40   // block columns from which the queue runs eight waves per workgroup (chol_tasks8_kernel)
 #define ALABI_CHOL_PLAIN_MIN 4   // block columns per UPDATE from which its operands are read with ordinary loads behind one acquire
 
@@ -787,10 +787,13 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, 
         }
         return true;
     };
+    // (Measured and not kept: a grouped UPDATE drawing the NEXT task under its last block column, to take the queue's atomic round
+    // trip off the workgroup's path -- still deadlock-free, and the four-wave kernel gained 3 % at N >= 5000, but the eight-wave
+    // kernel lost 1-9 % at every size: a CHAIN task drawn ahead waits for its holder.)
     for (;;) {
-        if (NT == 512) {
-            // 256 registers per lane: the per-thread tile offsets of every task type must not be hoisted out of the task loop (the
-            // compiler then keeps ~115 loop-invariant addresses and spills them) -- they are re-derived per task from an opaque tid
+        {
+            // the per-thread tile offsets of every task type must not be hoisted out of the task loop (the compiler then keeps ~115
+            // loop-invariant addresses alive and, with 256 registers per lane, spills them): re-derived per task from an opaque tid
             asm volatile("" : "+v"(tid));
             w = tid >> 6; l = tid & 63; lr = l & 15; lk = l >> 4;
         }
@@ -1178,7 +1181,9 @@ static int chol_task_list(int nb, const CholTask** dev, int* count) {
 int cholesky_tasks_prepare(alabi_gp* gp, hipStream_t s, int* ctl_ints_out) {
     *ctl_ints_out = 0;
     const int nb = gp->Npad / 64;
-    // Default for 16..160 block columns (N = 961..10240; ALABI_CHOL_TASKS=0 / 1 forces it off / on for 3..256).  Measured
+    // Default for 16..256 block columns (N = 961..16384; ALABI_CHOL_TASKS=0 / 1 forces it off / on for 3..256).  With the eight-wave
+    // kernel of round 3 (from 40 block columns on): N = 5000 1.79 ms, 8192 5.08, 10000 8.5 (39.2 TFLOP/s), 11000 10.9 (panels of 8:
+    // 12.6), 12000 13.6 (15.4), 14000 20.6 (22.9), 16000 29.7 (30.6) -- profiles/r03_cholesky_w8_vs_w4.txt.  Before that: measured
     // (tools/prof_chol_tasks.py, assembly included; round 3, updates over groups of block columns): N = 1024 0.33 ms (0.46 launch
     // per step), 2000 0.59 (0.89), 3072 0.96 (1.39), 4096 1.40 (2.05), 5000 2.0 (2.9), 6000 2.86 (3.96), 8192 5.9 (6.9),
     // 10000 9.9 (10.8 panels of 8), 12000 15.9 (15.4), 16000 35.1 (30.5): from 11000 on the rank-512 panel path is ahead.
