@@ -787,6 +787,9 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, 
         }
         return true;
     };
+    // (Measured and not kept, round 3: CHAIN(k) applying block column k-2 to its panel tile itself instead of waiting for the
+    // one-column UPDATE(k,k-1,k-2) task -- N = 2000 0.55 -> 0.58 ms with four waves, 0.54 -> 0.55 with eight: the period of the
+    // chain is set by the 64-pivot factorisation handing its slabs to the next panel solve, not by that task.)
     // (Measured and not kept: a grouped UPDATE drawing the NEXT task under its last block column, to take the queue's atomic round
     // trip off the workgroup's path -- still deadlock-free, and the four-wave kernel gained 3 % at N >= 5000, but the eight-wave
     // kernel lost 1-9 % at every size: a CHAIN task drawn ahead waits for its holder.)
