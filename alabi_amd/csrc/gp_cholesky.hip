@@ -626,10 +626,6 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
     if (bad != 0 && lane == 0) atomicCAS(info, 0, kb * 64 + bad);
     return potrf_dinv(lll);
 }
-// One ds_read_b64 that the compiler will not pair with a neighbour into a ds_read2_b64 (volatile, LDS address space)
-__device__ inline double lds_read_b64(const double* p) {
-    return *(const volatile __attribute__((address_space(3))) double*)p;
-}
 // A tile in flight: all 16 loads of a thread are issued before the first one is consumed (several tiles are fetched
 // back to back and only then written to LDS: one memory round trip instead of one per tile)
 template <int NT> struct TileRegs { unsigned long long v[4096 / NT]; };

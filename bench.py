@@ -218,6 +218,12 @@ def config_extras():
             torch.cuda.synchronize(); t0 = time.perf_counter()
             gp.compute(cfg["X"]); torch.cuda.synchronize()
             fit_ms = 1e3 * (time.perf_counter() - t0)
+            refit_ms = None                                    # K assembly + Cholesky once everything is allocated (best of 3)
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                gp.compute(cfg["X"]); torch.cuda.synchronize()
+                dt_ms = 1e3 * (time.perf_counter() - t0)
+                refit_ms = dt_ms if refit_ms is None else min(refit_ms, dt_ms)
             s = EnsembleSampler(cfg["W"], cfg["d"], gp, cfg["y"], cfg["bounds"], seed=5)
             s.run_mcmc(cfg["p0"], 32, store=False)
             torch.cuda.synchronize()
@@ -234,7 +240,8 @@ def config_extras():
             entry = {"N_train": cfg["N"], "d": cfg["d"], "walkers": cfg["W"], "steps": steps, "path": s.last_path,
                      "kernel": s.last_stream_kernel or "ens_half_kernel / ens_half_multi_kernel",
                      "samples_per_s": cfg["W"] * steps / (best * 1e-3), "us_per_half_step": 1e3 * best / (2 * steps),
-                     "fit_ms_first_call": fit_ms, "acceptance_fraction": None}
+                     "fit_ms_first_call": fit_ms, "cholesky_assemble_ms": refit_ms,
+                     "cholesky_tflops": (cfg["N"] ** 3 / 3.0) / (refit_ms * 1e-3) / 1e12, "acceptance_fraction": None}
             # algorithmic fp64 work of the kernel sums: W/2 proposals x N points x (2d + 3) per half step
             entry["tflops"] = (cfg["W"] / 2.0) * cfg["N"] * (2 * cfg["d"] + 3) / (entry["us_per_half_step"] * 1e-6) / 1e12
             entry["roofline_frac_fp64"] = entry["tflops"] / FP64_PEAK_TFLOPS
@@ -538,7 +545,7 @@ def main():
             extras["roofline_cholesky"] = {"bound": "mfma", "achieved": ch_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                            "frac": ch_tf / FP64_PEAK_TFLOPS, "kernel": "chol_tasks_kernel (one launch, tile tasks with slab-wise hand-over; N^3/3 flops, assembly included in the time)",
                                            "counters": pmc_summary("chol_tasks_kernel", "mean"),
-                                           "note": "N=2000 is latency-bound on the chain of 31 diagonal factorisations; N=10000: 30 TFLOP/s, N=16000: 44 TFLOP/s on the panel path (DESIGN.md par. 7, profiles/r02_cholesky_*)"}
+                                           "note": "N=2000 is latency-bound on the chain of 31 diagonal factorisations; the larger sizes are timed in extras.configs (C4: N=5000, C5: N=10000, chol_tasks8_kernel: 39 TFLOP/s; N=16000: 46 TFLOP/s; DESIGN.md par. 7, profiles/r03_cholesky_w8_vs_w4.txt)"}
             if args.config == "C3" and not shard:
                 t_cfg = time.perf_counter()
                 extras["configs"] = config_extras()
