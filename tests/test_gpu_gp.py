@@ -599,14 +599,17 @@ def test_cholesky_panel_path(torch_gpu, monkeypatch, N, panel):
     assert np.max(np.abs(facs["panel"][2][1] - facs["rank64"][2][1])) <= 1e-8 * np.exp(h["log_amp"])
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("N", [130, 200, 705, 2000, 4096, 5200])
-def test_cholesky_task_queue(torch_gpu, monkeypatch, N):
-    """Up to 64 block columns the factorisation is ONE launch: persistent workgroups draw tile tasks (chain / panel solve /
+def test_cholesky_task_queue(torch_gpu, monkeypatch, N, waves):
+    """Up to 256 block columns the factorisation is ONE launch: persistent workgroups draw tile tasks (chain / panel solve /
     update) from a queue and hand tiles over through versioned write-through stores.  Same factor as the launch-per-step path
     to rounding, K reproduced, a non-positive-definite matrix reported with LAPACK's pivot index, and a wait that runs out
-    falls back to the step-by-step path with the same result."""
+    falls back to the step-by-step path with the same result.  Both kernels at every size: four waves per workgroup
+    (chol_tasks_kernel, the default below 40 block columns) and eight (chol_tasks8_kernel: four helper waves in the updates)."""
     from alabi_amd import HipGP
     from oracle.gp_oracle import OracleGP
+    monkeypatch.setenv("ALABI_CHOL_W8", "1" if waves == 8 else "0")
     X, y, h = make_problem(N, 6, 70 + N)
     o = OracleGP(6, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"])
     K = o.get_matrix(X)
@@ -637,3 +640,18 @@ def test_cholesky_task_queue(torch_gpu, monkeypatch, N):
         g2 = HipGP(6, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g2.compute(X)
         assert np.array_equal(g2.solver.get_factor().cpu().numpy(), facs["steps"][0])
         monkeypatch.delenv("ALABI_CHOL_SPIN_LIMIT")
+
+
+def test_cholesky_task_queue_four_and_eight_waves_same_bits(torch_gpu, monkeypatch):
+    """chol_tasks8_kernel splits a 64 x 64 update tile over eight waves (16 rows x 32 columns each) instead of four (16 x 64):
+    every output element still receives its k-steps in the same order, so the factors are bit-identical (N = 3000: 47 block
+    columns, grouped updates over 8 block columns and a near band of one-column updates)."""
+    from alabi_amd import HipGP
+    X, y, h = make_problem(3000, 5, 11)
+    monkeypatch.setenv("ALABI_CHOL_TASKS", "1")
+    facs = []
+    for w8 in ("0", "1"):
+        monkeypatch.setenv("ALABI_CHOL_W8", w8)
+        g = HipGP(5, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+        facs.append(g.solver.get_factor().cpu().numpy())
+    assert np.array_equal(facs[0], facs[1])
