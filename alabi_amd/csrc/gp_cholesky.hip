@@ -67,6 +67,11 @@ __device__ inline double pivot_rsqrt(double piv) {
 // pivot: a non-positive or non-finite pivot turns its own and every later column into NaN (rsq of it is NaN or inf, 0 * inf
 // = NaN), the earlier columns stay finite, so the FIRST diagonal entry that is not > 0 afterwards is LAPACK's `info`
 // (potrf_first_bad).
+// (Round 3, measured and not kept: the multipliers L[c0+k][c0+j], k >= j + 2, as uniform-address LDS reads of the just-scaled
+// column instead of v_readlane pairs, with the reciprocal square root of pivot j + 1 interleaved by hand with the updates of
+// pivot j -- bit-identical, a third fewer instructions, and the 64-pivot factorisation still takes 7.6 us = 285 cycles per
+// pivot: what sets the pace is the DEPENDENT chain of a pivot (readlane -> rsq -> four refinement operations -> scale ->
+// readlane -> FMA, ~10 links of 25-30 cycles each), not the instruction count the round-2 text blamed.)
 __device__ inline void potrf_slab(double (&a)[16], int c0) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
