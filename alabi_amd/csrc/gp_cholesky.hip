@@ -67,11 +67,14 @@ __device__ inline double pivot_rsqrt(double piv) {
 // pivot: a non-positive or non-finite pivot turns its own and every later column into NaN (rsq of it is NaN or inf, 0 * inf
 // = NaN), the earlier columns stay finite, so the FIRST diagonal entry that is not > 0 afterwards is LAPACK's `info`
 // (potrf_first_bad).
-// (Round 3, measured and not kept: the multipliers L[c0+k][c0+j], k >= j + 2, as uniform-address LDS reads of the just-scaled
+// (Round 3, measured and not kept: (i) the multipliers L[c0+k][c0+j], k >= j + 2, as uniform-address LDS reads of the just-scaled
 // column instead of v_readlane pairs, with the reciprocal square root of pivot j + 1 interleaved by hand with the updates of
-// pivot j -- bit-identical, a third fewer instructions, and the 64-pivot factorisation still takes 7.6 us = 285 cycles per
-// pivot: what sets the pace is the DEPENDENT chain of a pivot (readlane -> rsq -> four refinement operations -> scale ->
-// readlane -> FMA, ~10 links of 25-30 cycles each), not the instruction count the round-2 text blamed.)
+// pivot j -- bit-identical, no faster; (ii) the trailing columns updated from the UNSCALED column and 1 / pivot, which shortens
+// the dependent chain from pivot to pivot from two cross-lane hops + eight operations to one hop + six but adds four
+// instructions per pivot -- 7.6 -> 8.0 us for the 64-pivot factorisation.  Data-dependent s_memrealtime stamps (ALABI_CHOL_PROF)
+// then put wave 0's slab recurrence at 1.1-1.2 us per 16 pivots = 172 cycles per pivot for ~31 instructions: a lone wave issues
+// one instruction per ~5.5 cycles and the recurrence is bound by that COUNT, as the round-2 text says; the four recurrences are
+// 4.6 of the factorisation's 7.5 us, the rank-16 updates between them, their barriers and the slab's LDS traffic the rest.)
 __device__ inline void potrf_slab(double (&a)[16], int c0) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -583,6 +586,9 @@ __device__ __attribute__((noinline)) void ct_trsm_upd() {
 // task consumes L[k,k] in exactly that order -- so wave 3, idle while wave 0 runs the next recurrence, writes the slab (and
 // its 16 reciprocals) through to memory and, one barrier later when its stores have drained, publishes sver[k] = slab + 1.
 // The next CHAIN task then solves slab s while this one factorises slab s + 1 .. 3 instead of starting after the whole tile.
+#ifdef ALABI_CHOL_PROF
+__device__ long long g_potrf_prof[2];                          // 10-ns ticks inside wave 0's slab recurrences, slabs
+#endif
 __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, double* __restrict__ D, int ld, double* __restrict__ dinv,
                                                             int* sver) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -594,7 +600,22 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
             double a[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) a[j] = ct_T0[lane][c0 + j];
+#ifdef ALABI_CHOL_PROF
+            long long q0_, q1_;
+            {   // stamps that depend on the data: after the slab is in registers / after its last entry is final
+                const int dep_ = __builtin_amdgcn_readfirstlane(__double2hiint(a[0]) ^ __double2hiint(a[15]));
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q0_) : "s"(dep_) : "memory");
+                asm volatile("" : "+v"(a[0]), "+v"(a[15]) : "s"(q0_));
+            }
+#endif
             potrf_slab(a, c0);
+#ifdef ALABI_CHOL_PROF
+            {
+                const int dep_ = __builtin_amdgcn_readfirstlane(__double2hiint(a[15]));
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q1_) : "s"(dep_) : "memory");
+            }
+            if (lane == 0) { g_potrf_prof[0] += q1_ - q0_; g_potrf_prof[1] += 1; }
+#endif
 #pragma unroll
             for (int j = 0; j < 16; ++j) ct_T0[lane][c0 + j] = a[j];
         } else if (w == 3 && s > 0) {                          // slab s - 1 was written out in the previous round: publish it
@@ -1237,6 +1258,13 @@ int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
                 fprintf(stderr, "[chol_tasks_kernel] per %s UPDATE (us): wait for deps %.2f, first fetch + C %.2f, loop %.2f (%.2f per block column), C store + publish %.2f (n=%lld, %.2f columns each)\n",
                         q == 8 ? "grouped" : "single-column", 0.01 * h[q] / h[q + 4], 0.01 * h[q + 1] / h[q + 4], 0.01 * h[q + 2] / h[q + 4],
                         0.01 * h[q + 2] / (h[q + 5] ? h[q + 5] : 1), 0.01 * h[q + 3] / h[q + 4], h[q + 4], (double)h[q + 5] / h[q + 4]);
+        {
+            long long pp[2] = {0, 0};
+            (void)hipMemcpyFromSymbol(pp, HIP_SYMBOL(g_potrf_prof), sizeof(pp));
+            if (pp[1] > 0) fprintf(stderr, "[chol_tasks_kernel] slab recurrence of the diagonal factorisation (wave 0): %.2f us per 16 pivots (n=%lld)\n", 0.01 * pp[0] / pp[1], pp[1]);
+            long long z[2] = {0, 0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_potrf_prof), z, sizeof(z));
+        }
         if (h[6] > 0)
             fprintf(stderr, "[chol_tasks_kernel] per CHAIN (us): wait %.2f loads %.2f trsm %.2f store+publish %.2f mfma %.2f potrf %.2f store+publish %.2f (n=%lld)\n",
                     0.01 * h[7] / h[6], 0.01 * h[0] / h[6], 0.01 * h[1] / h[6], 0.01 * h[2] / h[6], 0.01 * h[3] / h[6], 0.01 * h[4] / h[6],
