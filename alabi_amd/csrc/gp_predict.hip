@@ -898,7 +898,8 @@ template <int KS, bool GENERIC>
 __global__ void __launch_bounds__(256)
 predict_mean_mfma_kernel(const double* __restrict__ Xa, const double* __restrict__ alpha, int Npad,
                          const double* __restrict__ Xs, int d, long long M, DimVec inv_len, const double* __restrict__ centre,
-                         double amp, double mean, KernelFn kf, double* __restrict__ mu) {
+                         double amp, double mean, KernelFn kf, double* __restrict__ mu, double* __restrict__ mu_part, long long mu_stride,
+                         int pts_per_part) {
     __shared__ double etab[256];                                 // 2^(j/256) for exp2s_tab256
     etab[threadIdx.x] = exp2((double)threadIdx.x * 0.00390625);
     __syncthreads();
@@ -934,7 +935,10 @@ predict_mean_mfma_kernel(const double* __restrict__ Xa, const double* __restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) sum[qt][i] = 0.0;
     const double* xb = Xa + (size_t)lk * Npad + lr;       // B operand: point column lr of the tile, coordinate 4 s + lk
-    for (int n0 = 0; n0 < Npad; n0 += 16) {
+    // gridDim.y > 1 (medium batches: too few 256-query workgroups to fill the chip): the training points are dealt to gridDim.y
+    // workgroups per query block in runs of pts_per_part (a multiple of 16); mean_combine_kernel adds the parts in order
+    const int n_lo = blockIdx.y * pts_per_part, n_hi = (n_lo + pts_per_part < Npad) ? n_lo + pts_per_part : Npad;
+    for (int n0 = n_lo; n0 < n_hi; n0 += 16) {
         double b[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) b[s] = xb[(size_t)(4 * s) * Npad + n0];
@@ -962,7 +966,10 @@ predict_mean_mfma_kernel(const double* __restrict__ Xa, const double* __restrict
             v += dpp_move<0x114, 0xf>(v);
             v += dpp_move<0x118, 0xf>(v);
             const long long m = q0 + 16 * qt + lk + 4 * i;
-            if (lr == 15 && m < M) mu[m] = fma(amp, v, mean);
+            if (lr == 15 && m < M) {
+                if (mu_part) mu_part[(size_t)blockIdx.y * mu_stride + m] = v;
+                else mu[m] = fma(amp, v, mean);
+            }
         }
 }
 
@@ -998,15 +1005,38 @@ int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu,
     const int db = dim_bucket(gp->d);
     const double amp = exp(gp->log_amp);
     const char* mf = getenv("ALABI_PM_MFMA");
-    // batches that fill the chip with 256-query workgroups and d + 2 <= 32: the matrix-core kernel
-    if (M >= 32768 && gp->d + 2 <= 32 && !(mf && mf[0] == '0')) {
+    // d + 2 <= 32 and at least 2048 queries: the matrix-core kernel.  256-query workgroups alone fill the chip from ~200 000 queries
+    // on; below that (round 3) the training points are split over `parts` workgroups per query block as well, three workgroups
+    // per CU in all, and mean_combine_kernel adds the parts.  Measured at N = 2000, d = 10 (vector kernels before -> now):
+    // 2048 queries 28 -> 21 us, 4096 53 -> 25, 10^4 48 -> 38, 16384 63 -> 47, 32768 113 (unsplit matrix-core kernel) -> 79,
+    // 65536 192 -> 139; N = 5000: 10^4 queries 104 -> 77 us; N = 10000, d = 20: 310 -> 203 us (gpurun_out/s2_pm_split*.txt)
+    if (M >= 2048 && gp->d + 2 <= 32 && !(mf && mf[0] == '0')) {
         int st = ensure_xa(gp, s);
         if (st != ALABI_OK) return st;
         const int ks = (gp->d + 2 + 3) / 4;
         const long long wgs = (M + 255) / 256;
         if (wgs > 0x7fffffffLL) return ALABI_BAD_ARGUMENT;
-        ALABI_DISPATCH_KS(ks, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_mean_mfma_kernel<KS, GENERIC>), dim3((unsigned)wgs),
-            dim3(256), 0, s, gp->Xa, gp->alpha, gp->Npad, Xs, gp->d, M, gp->inv_len, gp->xa_centre, amp, gp->mean, gp->kf, mu)));
+        int dev = 0, n_cu = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        int parts = 1, pts = gp->Npad;
+        const long long per_cu = 3;
+        if (wgs < per_cu * n_cu) {
+            parts = (int)((per_cu * n_cu + wgs - 1) / wgs);
+            const int tiles16 = gp->Npad / 16;
+            if (parts > tiles16 / 4) parts = tiles16 / 4;            // at least four 16-point tiles per part
+            if (parts < 1) parts = 1;
+            pts = ((tiles16 + parts - 1) / parts) * 16;
+            parts = (gp->Npad + pts - 1) / pts;
+        }
+        const long long mu_stride = wgs * 256;
+        if (parts > 1 && (st = ensure_mupart(gp, (size_t)parts * mu_stride * sizeof(double), s)) != ALABI_OK) return st;
+        ALABI_DISPATCH_KS(ks, ALABI_DISPATCH_KERNEL(gp->kf.type, hipLaunchKernelGGL((predict_mean_mfma_kernel<KS, GENERIC>), dim3((unsigned)wgs, parts),
+            dim3(256), 0, s, gp->Xa, gp->alpha, gp->Npad, Xs, gp->d, M, gp->inv_len, gp->xa_centre, amp, gp->mean, gp->kf, mu,
+            parts > 1 ? gp->mupart : (double*)nullptr, mu_stride, pts)));
+        if (parts > 1)
+            hipLaunchKernelGGL(mean_combine_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, gp->mupart, parts, mu_stride, M, amp,
+                               gp->mean, mu);
         ALABI_LAUNCH_CHECK();
         return ALABI_OK;
     }

@@ -539,7 +539,7 @@ def main():
                                               "counters": pmc_summary("predict_var_w2_kernel")}
             pm_tf = extras["predict_mean_pts_per_s_M1e6"] * N * (2 * d + 3) / 1e12
             extras["roofline_predict_mean"] = {"bound": "fp64-valu", "achieved": pm_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                               "frac": pm_tf / FP64_PEAK_TFLOPS, "kernel": "predict_mean_mfma_kernel (M >= 32768; predict_mean_tile_kernel below)",
+                                               "frac": pm_tf / FP64_PEAK_TFLOPS, "kernel": "predict_mean_mfma_kernel (M >= 2048, training points split over workgroups below ~2e5 queries; predict_mean_rowwise_kernel below)",
                                                "flops_per_point": N * (2 * d + 3), "counters": pmc_summary("predict_mean_mfma_kernel<")}
             ch_tf = extras["cholesky_gflops"] / 1e3
             extras["roofline_cholesky"] = {"bound": "mfma", "achieved": ch_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
