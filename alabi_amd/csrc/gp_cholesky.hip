@@ -525,7 +525,8 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
 // Order per block column k: CHAIN(k+1) first, then the panel solves, then the updates of column k+1 (the next chain's
 // inputs), then the rest -- the chain never queues behind bulk updates.  ver[i][j] = number of steps applied to tile (i, j);
 // j + 1 means final.
-// type & 255: 0 CHAIN(k), 1 TRSM(i,k), 2 UPDATE(i,j,k..k+cnt-1) with cnt = type >> 8 consecutive block columns (chol_build_tasks)
+// type & 255: 0 CHAIN(k), 1 TRSM(i,k), 2 UPDATE(i,j,k..k+cnt-1) with cnt = type >> 8 consecutive block columns (chol_build_tasks),
+//             4 UPDATE2 = UPDATE(i,j,..) and UPDATE(i+1,j,..) in one task (eight-wave kernel)
 struct CholTask { int type, i, j, k; };
 #define ALABI_CHOL_TASKS_MAX_NB 256   // default upper end of the one-launch task queue (N <= 16384); beyond: panels of 8 block columns
 #define ALABI_CHOL_W8_MIN_NB 40   // block columns from which the queue runs eight waves per workgroup (chol_tasks8_kernel)
@@ -561,10 +562,11 @@ __device__ inline void publish_version(int* ver, int value, int tid) {
 // Module-scope LDS, named directly by the non-inlined phase functions (as pointer arguments they would degrade to generic
 // pointers).  The panel solve and the diagonal factorisation are separate noinline functions: inlined into the task loop their
 // live ranges merge with the loop's and the serial recurrences fill up with AGPR moves (8.6 / 13.1 us instead of 5 / 9).
-__shared__ double ct_T0[64][66];
-__shared__ double ct_T1[64][66];
-__shared__ double ct_T2[64][66];                                      // CHAIN: the diagonal tile, parked while the panel tile is solved
-__shared__ double ct_T3[64][66];                                      // UPDATE over several block columns: second operand pair (T2, T3)
+__shared__ double ct_pool[4][64][66];                                 // one array: UPDATE2 views it as six 64 x 34 half tiles
+#define ct_T0 ct_pool[0]
+#define ct_T1 ct_pool[1]
+#define ct_T2 ct_pool[2]                                              // CHAIN: the diagonal tile, parked while the panel tile is solved
+#define ct_T3 ct_pool[3]                                              // UPDATE over several block columns: second operand pair (T2, T3)
 __shared__ double ct_di[64];
 // One 16-column slab of the panel solve (CHAIN: the slabs of L[k-1,k-1] arrive one by one, see ct_potrf_publish).
 // The slab's recurrence for all 64 rows of the tile by ONE wave (lane = row; the instruction stream is the same as for 16
@@ -835,7 +837,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, 
 #ifdef ALABI_CHOL_PROF
         const long long pw0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        // ---- dependencies: up to three (tile, version) pairs, polled by lanes 0..2 of wave 0
+        // ---- dependencies: up to five (tile, version) pairs, polled by lanes 0..4 of wave 0
         if (w == 0) {
             int di_ = 0, dj_ = 0, need = 0;                           // lane 0 / 1 / 2
             if (type == 0) {                                          // CHAIN(k): tile (k,k-1) and (k,k) at k-1
@@ -851,8 +853,12 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, 
                 if (l == 0) { di_ = ti; dj_ = kl; need = kl + 1; }
                 if (l == 1) { di_ = tj; dj_ = kl; need = kl + 1; }
                 if (l == 2) { di_ = ti; dj_ = tj; need = tk; }
+                if (type == 4) {                                      // UPDATE2: the same for tile row i + 1
+                    if (l == 3) { di_ = ti + 1; dj_ = kl; need = kl + 1; }
+                    if (l == 4) { di_ = ti + 1; dj_ = tj; need = tk; }
+                }
             }
-            const bool active = l < 3 && need > 0;
+            const bool active = l < 5 && need > 0;
             int spins = 0, ok = 1;
             while (true) {
                 int have = need;
@@ -868,7 +874,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, 
             // an UPDATE over a whole group of block columns streams its operand tiles with ordinary loads (they can hit in the XCD's
             // L2, where the neighbouring tasks of the same tile column have just put them; write-through-coherent loads always go
             // out to the fabric, and the bulk updates are bound by exactly that traffic): one acquire per task makes that valid
-            if (type == 2 && tcnt >= ALABI_CHOL_PLAIN_MIN) {
+            if ((type == 2 && tcnt >= ALABI_CHOL_PLAIN_MIN) || type == 4) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1003,6 +1009,108 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, 
                 atomicAdd(up + 4, 1ull); atomicAdd(up + 5, (unsigned long long)tcnt);
             }
 #endif
+        } else if (type == 4) {
+            // ---------------- UPDATE2(i, j, k .. k + tcnt - 1): the grouped update of tiles (i, j) AND (i + 1, j) in one task (eight-wave
+            // kernel only).  A 128 x 64 output: wave w owns rows 32 (w & 3) .., columns 32 (w >> 2) .. (2 x 2 accumulator tiles: two A
+            // and two B operand reads feed four matrix-core instructions, 1.0 LDS read per instruction instead of 1.5), the operand
+            // tile A(j, k') is fetched once for both rows, and the fixed cost of a task (queue draw, dependency poll, first fetch, C round
+            // trip, publish: 4.3 us) is paid once per two tiles.  Three operand tiles per block column do not fit twice beside each other
+            // in 135 KB, so a stage is HALF a block column (32 k-values): six 64 x 34 half tiles = two buffers in the pool; while the
+            // k-steps of half-stage s run, half-stage s + 1 goes from registers to the other buffer and s + 2 from memory into the same
+            // registers, piece by piece (six 16-byte pieces per thread: vmcnt(5) in front of each).  Every output element receives its
+            // k-steps in the same order as in UPDATE: the same bits.
+            if constexpr (NT == 512) {
+                double (*H)[34] = reinterpret_cast<double (*)[34]>(&ct_pool[0][0][0]);      // half tile q: rows 64 q .. 64 q + 63
+                const int wr2 = w & 3, wc = w >> 2;
+                const int prow = tid >> 3, pcol = 2 * (tid & 7);                             // this thread's piece of a half tile: 16 bytes
+                const unsigned rowb[3] = {(unsigned)(ti * 64 + prow) * (unsigned)ld * 8u, (unsigned)((ti + 1) * 64 + prow) * (unsigned)ld * 8u,
+                                          (unsigned)(tj * 64 + prow) * (unsigned)ld * 8u};
+                u32x4 pc[6];
+                auto request = [&](int p, int hs) {                                          // half-stage hs = 2 (block column) + half
+                    pc[p] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, rowb[p >> 1] + (unsigned)(((tk + (hs >> 1)) * 64 + 32 * (hs & 1) + 16 * (p & 1) + pcol) * 8), 0, 0);
+                };
+                auto to_lds = [&](int p, int buf) {
+                    *reinterpret_cast<u32x4*>(&H[(buf * 3 + (p >> 1)) * 64 + prow][16 * (p & 1) + pcol]) = pc[p];
+                };
+                const int nhs = 2 * tcnt;
+#pragma unroll
+                for (int p = 0; p < 6; ++p) request(p, 0);
+                double* C = A + (size_t)(ti * 64 + 32 * wr2) * ld + tj * 64 + 32 * wc;      // rows 32 wr2 .. of the 128-row pair
+                v4f64 acc[2][2];
+#pragma unroll
+                for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[ri][n][i] = __longlong_as_double((long long)__hip_atomic_load(
+                                reinterpret_cast<const unsigned long long*>(C + (size_t)(16 * ri + lk + 4 * i) * ld + 16 * n + lr), __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+                for (int p = 0; p < 6; ++p) to_lds(p, 0);
+#pragma unroll
+                for (int p = 0; p < 6; ++p) request(p, 1);                                    // (nhs >= 2 always)
+#pragma unroll
+                for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) asm volatile("" : "+v"(acc[ri][n]));        // C is waited for HERE
+                __syncthreads();
+                auto half_stage = [&](auto more_tag, auto more2_tag, int hs) {
+                    constexpr bool MORE = decltype(more_tag)::value, MORE2 = decltype(more2_tag)::value;
+                    const int buf = hs & 1;
+                    double (*Ha)[34] = H + (buf * 3 + (wr2 >> 1)) * 64 + 32 * (wr2 & 1);   // this wave's 32 rows of A(i) or A(i+1)
+                    double (*Hb)[34] = H + (buf * 3 + 2) * 64 + 32 * wc;                    // its 32 columns = rows of A(j)
+                    double pa[2][2][2], pb[2][2][2];
+                    auto lds_pair = [&](int set, int kp) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int kk = 4 * (2 * kp + h) + lk;
+                            pa[set][h][0] = lds_read_b64(&Ha[lr][kk]); pa[set][h][1] = lds_read_b64(&Ha[16 + lr][kk]);
+                            pb[set][h][0] = lds_read_b64(&Hb[lr][kk]); pb[set][h][1] = lds_read_b64(&Hb[16 + lr][kk]);
+                        }
+                    };
+                    lds_pair(0, 0);
+#pragma unroll
+                    for (int kp = 0; kp < 4; ++kp) {
+                        if (kp < 3) lds_pair((kp + 1) & 1, kp + 1);
+#pragma unroll
+                        for (int p = 2 * kp; p < 2 * kp + 2 && p < 6; ++p) {
+                            if (MORE) to_lds(p, buf ^ 1);
+                            if (MORE2) request(p, hs + 2);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                                for (int n = 0; n < 2; ++n)
+                                    acc[ri][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[kp & 1][h][ri], pb[kp & 1][h][n], acc[ri][n], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                for (int hs = 0; hs < nhs; ++hs) {
+                    const bool more = hs + 1 < nhs;
+                    if (hs + 2 < nhs) half_stage(std::true_type{}, std::true_type{}, hs);
+                    else if (more) half_stage(std::true_type{}, std::false_type{}, hs);
+                    else half_stage(std::false_type{}, std::false_type{}, hs);
+                    if (more) __syncthreads();
+                }
+#pragma unroll
+                for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            __hip_atomic_store(reinterpret_cast<unsigned long long*>(C + (size_t)(16 * ri + lk + 4 * i) * ld + 16 * n + lr),
+                                               (unsigned long long)__double_as_longlong(acc[ri][n][i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_store(ver + ti * nb + tj, tk + tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ver + (ti + 1) * nb + tj, tk + tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else if (type == 1) {
             // ---------------- TRSM(i, k)
             {
@@ -1137,7 +1245,7 @@ static int tiles_in_cols(int ntr, int tc0, int tc1) {
 //   catches up in one task when the chain is near + 1 columns away, and from then on takes every block column as soon as it is
 //   final, so that nothing the chain needs waits for a group to fill.
 // Every task depends only on tasks before it in the list (tests/test_abi.py replays the order on the host).
-static void chol_build_tasks(int nb, int gk, int near, std::vector<CholTask>& t) {
+static void chol_build_tasks(int nb, int gk, int near, bool two, std::vector<CholTask>& t) {
     auto far = [&](int j) { return (j - near) < 0 ? 0 : (j - near) / gk * gk; };
     t.clear();
     t.push_back({0, 0, 0, 0});
@@ -1148,12 +1256,15 @@ static void chol_build_tasks(int nb, int gk, int near, std::vector<CholTask>& t)
         for (int j = k + 2; j < nb && j <= k + near; ++j)
             for (int i = j; i < nb; ++i) t.push_back({2 | (1 << 8), i, j, k});
         const int jc = k + 1 + near;                          // catches up: block columns [far(jc), k]
-        if (jc < nb && far(jc) <= k)
+        if (jc < nb && far(jc) <= k)                          // (one tile per task: as UPDATE2 pairs these cost 6 % at N = 10000 -- the chain is near)
             for (int i = jc; i < nb; ++i) t.push_back({2 | ((k + 1 - far(jc)) << 8), i, jc, far(jc)});
         if ((k + 1) % gk == 0)
             for (int j = k + 1 + near; j < nb; ++j) {
                 if (far(j) < k + 1) continue;                 // (j = k+1+near has far(j) = k+1 here: its catch-up task above is empty)
-                for (int i = j; i < nb; ++i) t.push_back({2 | (gk << 8), i, j, k + 1 - gk});
+                for (int i = j; i < nb; ++i) {
+                    if (two && i + 1 < nb) { t.push_back({4 | (gk << 8), i, j, k + 1 - gk}); ++i; }   // tiles (i, j) and (i + 1, j)
+                    else t.push_back({2 | (gk << 8), i, j, k + 1 - gk});
+                }
             }
     }
 }
@@ -1167,11 +1278,22 @@ static void chol_task_shape(int nb, int* gk, int* near) {
     if (const char* e = getenv("ALABI_CHOL_NEAR")) { const int v = atoi(e); if (v >= 1 && v <= 16) *near = v; }
 }
 
+static bool chol_tasks_w8(int nb) {                       // eight waves per workgroup (chol_tasks8_kernel)?
+    bool w8 = nb >= ALABI_CHOL_W8_MIN_NB;
+    if (const char* e3 = getenv("ALABI_CHOL_W8")) w8 = e3[0] == '1';
+    return w8;
+}
+static bool chol_tasks_two(int nb, int gk) {              // grouped updates of two tiles per task (UPDATE2; eight-wave kernel, gk >= 2)
+    bool two = chol_tasks_w8(nb) && gk >= 2;
+    if (const char* e = getenv("ALABI_CHOL_UPDATE2")) two = two && e[0] != '0';
+    return two;
+}
+
 extern "C" int alabi_debug_chol_tasks(int nb, int* out, int cap) {   // host only: the list as (type, i, j, k) quadruples; returns the count
     int gk, near;
     chol_task_shape(nb, &gk, &near);
     std::vector<CholTask> t;
-    chol_build_tasks(nb, gk, near, t);
+    chol_build_tasks(nb, gk, near, chol_tasks_two(nb, gk), t);
     if (out)
         for (size_t q = 0; q < t.size() && (int)q < cap; ++q) { out[4 * q] = t[q].type; out[4 * q + 1] = t[q].i; out[4 * q + 2] = t[q].j; out[4 * q + 3] = t[q].k; }
     return (int)t.size();
@@ -1184,12 +1306,13 @@ static int chol_task_list(int nb, const CholTask** dev, int* count) {
     int device = 0, gk, near;
     ALABI_HIP_CHECK(hipGetDevice(&device));
     chol_task_shape(nb, &gk, &near);
+    const bool two = chol_tasks_two(nb, gk);
     std::lock_guard<std::mutex> lk(mu);
-    const std::array<int, 4> key{device, nb, gk, near};
+    const std::array<int, 4> key{device, nb, gk, near + (two ? 64 : 0)};
     auto it = cache.find(key);
     if (it == cache.end()) {
         std::vector<CholTask> t;
-        chol_build_tasks(nb, gk, near, t);
+        chol_build_tasks(nb, gk, near, two, t);
         CholTask* d = nullptr;
         ALABI_HIP_CHECK(hipMalloc(&d, t.size() * sizeof(CholTask)));
         ALABI_HIP_CHECK(hipMemcpy(d, t.data(), t.size() * sizeof(CholTask), hipMemcpyHostToDevice));
@@ -1243,8 +1366,7 @@ int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
     int spin = 1 << 18;
     if (const char* e2 = getenv("ALABI_CHOL_SPIN_LIMIT")) { const int v = atoi(e2); if (v > 0) spin = v; }
     // eight waves per workgroup from ALABI_CHOL_W8_MIN_NB block columns on (ALABI_CHOL_W8=0 / 1 forces four / eight)
-    bool w8 = nb >= ALABI_CHOL_W8_MIN_NB;
-    if (const char* e3 = getenv("ALABI_CHOL_W8")) w8 = e3[0] == '1';
+    const bool w8 = chol_tasks_w8(nb);
     if (w8) hipLaunchKernelGGL(chol_tasks8_kernel, dim3(grid), dim3(512), 0, s, gp->L, ld, nb, tasks, ntasks, gp->chol_ctl, gp->info, gp->dinv, spin);
     else hipLaunchKernelGGL(chol_tasks_kernel, dim3(grid), dim3(256), 0, s, gp->L, ld, nb, tasks, ntasks, gp->chol_ctl, gp->info, gp->dinv, spin);
     ALABI_LAUNCH_CHECK();

@@ -53,8 +53,9 @@ def test_product_does_not_import_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
 
 
+@pytest.mark.parametrize("w8", ["0", "1"])
 @pytest.mark.parametrize("gk,near", [(4, 2), (1, 1), (8, 3), (2, 1), (3, 5)])
-def test_cholesky_task_list_is_a_topological_order(gk, near, monkeypatch):
+def test_cholesky_task_list_is_a_topological_order(gk, near, w8, monkeypatch):
     """The static task list of the one-launch Cholesky (alabi/core.py:1158 -> gp.compute): replayed in order on the host,
     every task finds its inputs produced by EARLIER tasks (a workgroup only ever waits for lower-numbered tasks: no deadlock),
     every tile receives every block column exactly once and in order, and every panel tile is solved exactly once."""
@@ -65,6 +66,7 @@ def test_cholesky_task_list_is_a_topological_order(gk, near, monkeypatch):
     lib.alabi_debug_chol_tasks.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
     monkeypatch.setenv("ALABI_CHOL_GK", str(gk))
     monkeypatch.setenv("ALABI_CHOL_NEAR", str(near))
+    monkeypatch.setenv("ALABI_CHOL_W8", w8)                  # the eight-wave kernel's list holds UPDATE2 tasks (two tiles per grouped update)
     for nb in (3, 5, 16, 33, 79):
         n = lib.alabi_debug_chol_tasks(nb, None, 0)
         buf = (ctypes.c_int * (4 * n))()
@@ -85,11 +87,13 @@ def test_cholesky_task_list_is_a_topological_order(gk, near, monkeypatch):
             elif ty == 1:                                    # TRSM(i, k)
                 assert j == k and i >= k + 2 and final[k][k] and ver[i][k] == k and not final[i][k]
                 final[i][k] = True
-            else:                                            # UPDATE(i, j, k .. k + cnt - 1)
-                assert ty == 2 and cnt >= 1 and i >= j > k + cnt - 1
-                assert not (i == j == k + cnt)               # the last column of a diagonal tile belongs to CHAIN
-                assert ver[i][j] == k and final[i][k + cnt - 1] and final[j][k + cnt - 1]
-                ver[i][j] = k + cnt
+            else:                                            # UPDATE(i, j, k .. k + cnt - 1); UPDATE2 = the same for tile rows i and i + 1
+                assert ty in (2, 4) and cnt >= 1 and i >= j > k + cnt - 1
+                assert ty == 2 or (cnt >= 2 and i + 1 < nb)
+                for r in ((i,) if ty == 2 else (i, i + 1)):
+                    assert not (r == j == k + cnt)           # the last column of a diagonal tile belongs to CHAIN
+                    assert ver[r][j] == k and final[r][k + cnt - 1] and final[j][k + cnt - 1]
+                    ver[r][j] = k + cnt
         for i in range(nb):
             for j in range(i + 1):
                 assert final[i][j] and ver[i][j] == j, (nb, i, j)
