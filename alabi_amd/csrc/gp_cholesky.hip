@@ -526,10 +526,12 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
 // inputs), then the rest -- the chain never queues behind bulk updates.  ver[i][j] = number of steps applied to tile (i, j);
 // j + 1 means final.
 // type & 255: 0 CHAIN(k), 1 TRSM(i,k), 2 UPDATE(i,j,k..k+cnt-1) with cnt = type >> 8 consecutive block columns (chol_build_tasks),
-//             4 UPDATE2 = UPDATE(i,j,..) and UPDATE(i+1,j,..) in one task (eight-wave kernel)
+//             4 UPDATE2 = UPDATE(i,j,..) and UPDATE(i+1,j,..) in one task (eight-wave kernel), 5 UPDATE4 = the 2 x 2 block of tiles
+//             (i,j), (i+1,j), (i,j+1), (i+1,j+1), i >= j + 1
 struct CholTask { int type, i, j, k; };
 #define ALABI_CHOL_TASKS_MAX_NB 256   // default upper end of the one-launch task queue (N <= 16384); beyond: panels of 8 block columns
 #define ALABI_CHOL_W8_MIN_NB 40   // block columns from which the queue runs eight waves per workgroup (chol_tasks8_kernel)
+#define ALABI_CHOL_UPDATE4_MIN_NB 100 // block columns from which the far updates take 2 x 2 tiles per task (UPDATE4; below: UPDATE2)
 #define ALABI_CHOL_PLAIN_MIN 4   // block columns per UPDATE from which its operands are read with ordinary loads behind one acquire
 
 
@@ -562,11 +564,11 @@ __device__ inline void publish_version(int* ver, int value, int tid) {
 // Module-scope LDS, named directly by the non-inlined phase functions (as pointer arguments they would degrade to generic
 // pointers).  The panel solve and the diagonal factorisation are separate noinline functions: inlined into the task loop their
 // live ranges merge with the loop's and the serial recurrences fill up with AGPR moves (8.6 / 13.1 us instead of 5 / 9).
-__shared__ double ct_pool[4][64][66];                                 // one array: UPDATE2 views it as six 64 x 34 half tiles
-#define ct_T0 ct_pool[0]
-#define ct_T1 ct_pool[1]
-#define ct_T2 ct_pool[2]                                              // CHAIN: the diagonal tile, parked while the panel tile is solved
-#define ct_T3 ct_pool[3]                                              // UPDATE over several block columns: second operand pair (T2, T3)
+__shared__ double ct_pool[8 * 64 * 34];                               // one array: four 64 x 66 tiles, or (UPDATE2 / UPDATE4) six / eight 64 x 34 half tiles
+#define ct_T0 (reinterpret_cast<double (*)[66]>(ct_pool))
+#define ct_T1 (reinterpret_cast<double (*)[66]>(ct_pool + 64 * 66))
+#define ct_T2 (reinterpret_cast<double (*)[66]>(ct_pool + 2 * 64 * 66))   // CHAIN: the diagonal tile, parked while the panel tile is solved
+#define ct_T3 (reinterpret_cast<double (*)[66]>(ct_pool + 3 * 64 * 66))   // UPDATE over several block columns: second operand pair (T2, T3)
 __shared__ double ct_di[64];
 // One 16-column slab of the panel solve (CHAIN: the slabs of L[k-1,k-1] arrive one by one, see ct_potrf_publish).
 // The slab's recurrence for all 64 rows of the tile by ONE wave (lane = row; the instruction stream is the same as for 16
@@ -837,7 +839,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, 
 #ifdef ALABI_CHOL_PROF
         const long long pw0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        // ---- dependencies: up to five (tile, version) pairs, polled by lanes 0..4 of wave 0
+        // ---- dependencies: up to eight (tile, version) pairs, polled by lanes 0..7 of wave 0
         if (w == 0) {
             int di_ = 0, dj_ = 0, need = 0;                           // lane 0 / 1 / 2
             if (type == 0) {                                          // CHAIN(k): tile (k,k-1) and (k,k) at k-1
@@ -853,12 +855,17 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, 
                 if (l == 0) { di_ = ti; dj_ = kl; need = kl + 1; }
                 if (l == 1) { di_ = tj; dj_ = kl; need = kl + 1; }
                 if (l == 2) { di_ = ti; dj_ = tj; need = tk; }
-                if (type == 4) {                                      // UPDATE2: the same for tile row i + 1
+                if (type >= 4) {                                      // UPDATE2 / UPDATE4: the same for tile row i + 1
                     if (l == 3) { di_ = ti + 1; dj_ = kl; need = kl + 1; }
                     if (l == 4) { di_ = ti + 1; dj_ = tj; need = tk; }
                 }
+                if (type == 5) {                                      // UPDATE4: and for tile column j + 1
+                    if (l == 5) { di_ = tj + 1; dj_ = kl; need = kl + 1; }
+                    if (l == 6) { di_ = ti; dj_ = tj + 1; need = tk; }
+                    if (l == 7) { di_ = ti + 1; dj_ = tj + 1; need = tk; }
+                }
             }
-            const bool active = l < 5 && need > 0;
+            const bool active = l < 8 && need > 0;
             int spins = 0, ok = 1;
             while (true) {
                 int have = need;
@@ -874,7 +881,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, 
             // an UPDATE over a whole group of block columns streams its operand tiles with ordinary loads (they can hit in the XCD's
             // L2, where the neighbouring tasks of the same tile column have just put them; write-through-coherent loads always go
             // out to the fabric, and the bulk updates are bound by exactly that traffic): one acquire per task makes that valid
-            if ((type == 2 && tcnt >= ALABI_CHOL_PLAIN_MIN) || type == 4) {
+            if ((type == 2 && tcnt >= ALABI_CHOL_PLAIN_MIN) || type >= 4) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1009,6 +1016,104 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, 
                 atomicAdd(up + 4, 1ull); atomicAdd(up + 5, (unsigned long long)tcnt);
             }
 #endif
+        } else if (type == 5) {
+            // ---------------- UPDATE4(i, j, k .. k + tcnt - 1): tiles (i, j), (i + 1, j), (i, j + 1), (i + 1, j + 1) in one task -- a 128 x 128
+            // output, wave w owning rows 32 (w & 3) .., columns 64 (w >> 2) .. (2 x 4 accumulator tiles: six operand reads feed eight
+            // matrix-core instructions), four operand tiles per block column for four output tiles, the fixed cost of a task once per
+            // four tiles.  Eight 64 x 34 half tiles (two buffers of four) fill the pool; otherwise as UPDATE2.  i >= j + 1, so that
+            // tile (i, j + 1) is in the lower triangle ((j + 1, j + 1) is a diagonal tile: its update is the whole symmetric tile).
+            if constexpr (NT == 512) {
+                double (*H)[34] = reinterpret_cast<double (*)[34]>(ct_pool);
+                const int wr2 = w & 3, wc = w >> 2;
+                const int prow = tid >> 3, pcol = 2 * (tid & 7);
+                const unsigned rowb[4] = {(unsigned)(ti * 64 + prow) * (unsigned)ld * 8u, (unsigned)((ti + 1) * 64 + prow) * (unsigned)ld * 8u,
+                                          (unsigned)(tj * 64 + prow) * (unsigned)ld * 8u, (unsigned)((tj + 1) * 64 + prow) * (unsigned)ld * 8u};
+                u32x4 pc[8];
+                auto request = [&](int p, int hs) {
+                    pc[p] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, rowb[p >> 1] + (unsigned)(((tk + (hs >> 1)) * 64 + 32 * (hs & 1) + 16 * (p & 1) + pcol) * 8), 0, 0);
+                };
+                auto to_lds = [&](int p, int buf) {
+                    *reinterpret_cast<u32x4*>(&H[(buf * 4 + (p >> 1)) * 64 + prow][16 * (p & 1) + pcol]) = pc[p];
+                };
+                const int nhs = 2 * tcnt;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) request(p, 0);
+                // C: rows 32 wr2 .. of the 128-row pair (tile i or i + 1), columns of tile j + wc
+                double* C = A + (size_t)(ti * 64 + 32 * wr2) * ld + (tj + wc) * 64;
+                v4f64 acc[2][4];
+#pragma unroll
+                for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[ri][n][i] = __longlong_as_double((long long)__hip_atomic_load(
+                                reinterpret_cast<const unsigned long long*>(C + (size_t)(16 * ri + lk + 4 * i) * ld + 16 * n + lr), __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+                for (int p = 0; p < 8; ++p) to_lds(p, 0);
+#pragma unroll
+                for (int p = 0; p < 8; ++p) request(p, 1);
+#pragma unroll
+                for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(acc[ri][n]));        // C is waited for HERE
+                __syncthreads();
+                auto half_stage = [&](auto more_tag, auto more2_tag, int hs) {
+                    constexpr bool MORE = decltype(more_tag)::value, MORE2 = decltype(more2_tag)::value;
+                    const int buf = hs & 1;
+                    double (*Ha)[34] = H + (buf * 4 + (wr2 >> 1)) * 64 + 32 * (wr2 & 1);   // this wave's 32 rows of A(i) or A(i+1)
+                    double (*Hb)[34] = H + (buf * 4 + 2 + wc) * 64;                         // its 64 columns = the rows of A(j) or A(j+1)
+                    double pa[2][2][2], pb[2][2][4];
+                    auto lds_pair = [&](int set, int kp) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int kk = 4 * (2 * kp + h) + lk;
+                            pa[set][h][0] = lds_read_b64(&Ha[lr][kk]); pa[set][h][1] = lds_read_b64(&Ha[16 + lr][kk]);
+#pragma unroll
+                            for (int n = 0; n < 4; ++n) pb[set][h][n] = lds_read_b64(&Hb[16 * n + lr][kk]);
+                        }
+                    };
+                    lds_pair(0, 0);
+#pragma unroll
+                    for (int kp = 0; kp < 4; ++kp) {
+                        if (kp < 3) lds_pair((kp + 1) & 1, kp + 1);
+#pragma unroll
+                        for (int p = 2 * kp; p < 2 * kp + 2; ++p) {
+                            if (MORE) to_lds(p, buf ^ 1);
+                            if (MORE2) request(p, hs + 2);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                                for (int n = 0; n < 4; ++n)
+                                    acc[ri][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[kp & 1][h][ri], pb[kp & 1][h][n], acc[ri][n], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                for (int hs = 0; hs < nhs; ++hs) {
+                    const bool more = hs + 1 < nhs;
+                    if (hs + 2 < nhs) half_stage(std::true_type{}, std::true_type{}, hs);
+                    else if (more) half_stage(std::true_type{}, std::false_type{}, hs);
+                    else half_stage(std::false_type{}, std::false_type{}, hs);
+                    if (more) __syncthreads();
+                }
+#pragma unroll
+                for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            __hip_atomic_store(reinterpret_cast<unsigned long long*>(C + (size_t)(16 * ri + lk + 4 * i) * ld + 16 * n + lr),
+                                               (unsigned long long)__double_as_longlong(acc[ri][n][i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid < 4)
+                __hip_atomic_store(ver + (ti + (tid & 1)) * nb + tj + (tid >> 1), tk + tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (type == 4) {
             // ---------------- UPDATE2(i, j, k .. k + tcnt - 1): the grouped update of tiles (i, j) AND (i + 1, j) in one task (eight-wave
             // kernel only).  A 128 x 64 output: wave w owns rows 32 (w & 3) .., columns 32 (w >> 2) .. (2 x 2 accumulator tiles: two A
@@ -1020,7 +1125,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, 
             // registers, piece by piece (six 16-byte pieces per thread: vmcnt(5) in front of each).  Every output element receives its
             // k-steps in the same order as in UPDATE: the same bits.
             if constexpr (NT == 512) {
-                double (*H)[34] = reinterpret_cast<double (*)[34]>(&ct_pool[0][0][0]);      // half tile q: rows 64 q .. 64 q + 63
+                double (*H)[34] = reinterpret_cast<double (*)[34]>(ct_pool);                  // half tile q: rows 64 q .. 64 q + 63
                 const int wr2 = w & 3, wc = w >> 2;
                 const int prow = tid >> 3, pcol = 2 * (tid & 7);                             // this thread's piece of a half tile: 16 bytes
                 const unsigned rowb[3] = {(unsigned)(ti * 64 + prow) * (unsigned)ld * 8u, (unsigned)((ti + 1) * 64 + prow) * (unsigned)ld * 8u,
@@ -1246,6 +1351,10 @@ static int tiles_in_cols(int ntr, int tc0, int tc1) {
 //   final, so that nothing the chain needs waits for a group to fill.
 // Every task depends only on tasks before it in the list (tests/test_abi.py replays the order on the host).
 static void chol_build_tasks(int nb, int gk, int near, bool two, std::vector<CholTask>& t) {
+    // 2 x 2 tiles per grouped update from ALABI_CHOL_UPDATE4_MIN_NB block columns on (measured: N = 3072 0.87 -> 0.94 ms, 5000 1.82 -> 1.88,
+    // 8192 5.09 -> 4.97, 10000 8.36 -> 8.13, 16000 28.9 -> 27.5: the big tasks pay when the trailing matrix is wide)
+    bool four = two && nb >= ALABI_CHOL_UPDATE4_MIN_NB;
+    if (const char* e = getenv("ALABI_CHOL_UPDATE4")) four = two && e[0] == '1';
     auto far = [&](int j) { return (j - near) < 0 ? 0 : (j - near) / gk * gk; };
     t.clear();
     t.push_back({0, 0, 0, 0});
@@ -1261,9 +1370,19 @@ static void chol_build_tasks(int nb, int gk, int near, bool two, std::vector<Cho
         if ((k + 1) % gk == 0)
             for (int j = k + 1 + near; j < nb; ++j) {
                 if (far(j) < k + 1) continue;                 // (j = k+1+near has far(j) = k+1 here: its catch-up task above is empty)
+                const int k0 = k + 1 - gk;
+                if (four && j + 1 < nb) {
+                    // tile columns j and j + 1 together: the diagonal tile (j, j) alone, then 2 x 2 blocks of tiles from row j + 1 on
+                    t.push_back({2 | (gk << 8), j, j, k0});
+                    int i = j + 1;
+                    for (; i + 1 < nb; i += 2) t.push_back({5 | (gk << 8), i, j, k0});
+                    if (i < nb) { t.push_back({2 | (gk << 8), i, j, k0}); t.push_back({2 | (gk << 8), i, j + 1, k0}); }
+                    ++j;
+                    continue;
+                }
                 for (int i = j; i < nb; ++i) {
-                    if (two && i + 1 < nb) { t.push_back({4 | (gk << 8), i, j, k + 1 - gk}); ++i; }   // tiles (i, j) and (i + 1, j)
-                    else t.push_back({2 | (gk << 8), i, j, k + 1 - gk});
+                    if (two && i + 1 < nb) { t.push_back({4 | (gk << 8), i, j, k0}); ++i; }            // tiles (i, j) and (i + 1, j)
+                    else t.push_back({2 | (gk << 8), i, j, k0});
                 }
             }
     }
@@ -1308,7 +1427,8 @@ static int chol_task_list(int nb, const CholTask** dev, int* count) {
     chol_task_shape(nb, &gk, &near);
     const bool two = chol_tasks_two(nb, gk);
     std::lock_guard<std::mutex> lk(mu);
-    const std::array<int, 4> key{device, nb, gk, near + (two ? 64 : 0)};
+    const char* e4 = getenv("ALABI_CHOL_UPDATE4");
+    const std::array<int, 4> key{device, nb, gk, near + (two ? 64 : 0) + (e4 ? (e4[0] == '1' ? 128 : 256) : 0)};
     auto it = cache.find(key);
     if (it == cache.end()) {
         std::vector<CholTask> t;

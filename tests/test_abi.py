@@ -88,12 +88,14 @@ def test_cholesky_task_list_is_a_topological_order(gk, near, w8, monkeypatch):
                 assert j == k and i >= k + 2 and final[k][k] and ver[i][k] == k and not final[i][k]
                 final[i][k] = True
             else:                                            # UPDATE(i, j, k .. k + cnt - 1); UPDATE2 = the same for tile rows i and i + 1
-                assert ty in (2, 4) and cnt >= 1 and i >= j > k + cnt - 1
+                assert ty in (2, 4, 5) and cnt >= 1 and i >= j > k + cnt - 1      # UPDATE4 = the 2 x 2 block of tiles from (i, j)
                 assert ty == 2 or (cnt >= 2 and i + 1 < nb)
-                for r in ((i,) if ty == 2 else (i, i + 1)):
-                    assert not (r == j == k + cnt)           # the last column of a diagonal tile belongs to CHAIN
-                    assert ver[r][j] == k and final[r][k + cnt - 1] and final[j][k + cnt - 1]
-                    ver[r][j] = k + cnt
+                assert ty != 5 or (i >= j + 1 and j + 1 < nb)
+                for c in ((j,) if ty != 5 else (j, j + 1)):
+                    for r in ((i,) if ty == 2 else (i, i + 1)):
+                        assert r >= c and not (r == c == k + cnt)   # lower triangle; the last column of a diagonal tile belongs to CHAIN
+                        assert ver[r][c] == k and final[r][k + cnt - 1] and final[c][k + cnt - 1]
+                        ver[r][c] = k + cnt
         for i in range(nb):
             for j in range(i + 1):
                 assert final[i][j] and ver[i][j] == j, (nb, i, j)

@@ -654,8 +654,13 @@ def test_cholesky_task_queue_four_and_eight_waves_same_bits(torch_gpu, monkeypat
     X, y, h = make_problem(3000, 5, 11)
     monkeypatch.setenv("ALABI_CHOL_TASKS", "1")
     facs = []
-    for w8 in ("0", "1"):
+    # four waves; eight waves with one / two (UPDATE2, the default at this size) / 2 x 2 (UPDATE4, the default from 100 block columns
+    # on) tiles per grouped update: every output element receives its k-steps in the same order in all of them
+    for w8, two, four in (("0", "1", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "1", "1")):
         monkeypatch.setenv("ALABI_CHOL_W8", w8)
+        monkeypatch.setenv("ALABI_CHOL_UPDATE2", two)
+        monkeypatch.setenv("ALABI_CHOL_UPDATE4", four)
         g = HipGP(5, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
         facs.append(g.solver.get_factor().cpu().numpy())
-    assert np.array_equal(facs[0], facs[1])
+    for f in facs[1:]:
+        assert np.array_equal(facs[0], f)
