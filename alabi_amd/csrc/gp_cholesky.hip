@@ -1350,6 +1350,10 @@ static int tiles_in_cols(int ntr, int tc0, int tc1) {
 //   catches up in one task when the chain is near + 1 columns away, and from then on takes every block column as soon as it is
 //   final, so that nothing the chain needs waits for a group to fill.
 // Every task depends only on tasks before it in the list (tests/test_abi.py replays the order on the host).
+// (Round 3, measured and not kept: a batch of grouped updates dealt over the following gk steps -- a share per step, in front of or
+// behind its one-column updates, each column's share flushed before anything else touches the column -- so that the one-column
+// tasks find their panel tiles solved instead of waiting 4.4 us each: N = 3072 0.84 -> 0.81 ms, but 8192 5.0 -> 5.55 and 10000
+// 8.1 -> 8.6-8.7 either way; a batch in one piece keeps the operand tiles of a tile column in the XCDs' L2s while they are used.)
 static void chol_build_tasks(int nb, int gk, int near, bool two, std::vector<CholTask>& t) {
     // 2 x 2 tiles per grouped update from ALABI_CHOL_UPDATE4_MIN_NB block columns on (measured: N = 3072 0.87 -> 0.94 ms, 5000 1.82 -> 1.88,
     // 8192 5.09 -> 4.97, 10000 8.36 -> 8.13, 16000 28.9 -> 27.5: the big tasks pay when the trailing matrix is wide)
