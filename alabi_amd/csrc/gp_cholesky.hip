@@ -530,7 +530,7 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
 //             (i,j), (i+1,j), (i,j+1), (i+1,j+1), i >= j + 1
 struct CholTask { int type, i, j, k; };
 #define ALABI_CHOL_TASKS_MAX_NB 256   // default upper end of the one-launch task queue (N <= 16384); beyond: panels of 8 block columns
-#define ALABI_CHOL_W8_MIN_NB 40   // block columns from which the queue runs eight waves per workgroup (chol_tasks8_kernel)
+#define ALABI_CHOL_W8_MIN_NB 16   // block columns from which the queue runs eight waves per workgroup (chol_tasks8_kernel)
 #define ALABI_CHOL_UPDATE4_MIN_NB 100 // block columns from which the far updates take 2 x 2 tiles per task (UPDATE4; below: UPDATE2)
 #define ALABI_CHOL_PLAIN_MIN 4   // block columns per UPDATE from which its operands are read with ordinary loads behind one acquire
 
@@ -581,9 +581,11 @@ __device__ __attribute__((noinline)) void ct_trsm_rec() {
 template <int S>
 __device__ __attribute__((noinline)) void ct_trsm_upd() {
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    if (w >= 4) return;                                        // the helper waves of the 8-wave kernel own no rows here
+    // wave w owns rows 16 (w & 3) ..; with eight waves the helper wave w + 4 takes every second of its column tiles
+    const int half = w >> 2, two = (int)(blockDim.x >> 9);     // two = 1 with eight waves
 #pragma unroll
-    for (int t = S + 1; t < 4; ++t) tile_update_16<66>(ct_T1, 16 * w, 16 * t, ct_T1, 16 * w, ct_T0, 16 * t, 16 * S, lane);
+    for (int t = S + 1; t < 4; ++t)
+        if ((((t - S - 1) & 1) & two) == half) tile_update_16<66>(ct_T1, 16 * (w & 3), 16 * t, ct_T1, 16 * (w & 3), ct_T0, 16 * t, 16 * S, lane);
 }
 // The diagonal factorisation of CHAIN(k) (potrf_tile_lds_wg on ct_T0) that hands its result on SLAB BY SLAB: the 16 columns
 // of a slab are final for all 64 rows as soon as wave 0 has run the slab's recurrence, and the panel solve of the next chain
@@ -596,6 +598,7 @@ __device__ long long g_potrf_prof[2];                          // 10-ns ticks in
 __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, double* __restrict__ D, int ld, double* __restrict__ dinv,
                                                             int* sver) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nwm = (int)(blockDim.x >> 6) - 1;               // 3 or 7: the rank-16 tile updates between slabs are dealt to ALL waves of the workgroup
     kb = __builtin_amdgcn_readfirstlane(kb);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -646,7 +649,7 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
         for (int ti = s + 1; ti < 4; ++ti)
 #pragma unroll
             for (int tk = s + 1; tk <= ti; ++tk, ++t)
-                if ((t & 3) == w) tile_update_16<66>(ct_T0, 16 * ti, 16 * tk, ct_T0, 16 * ti, ct_T0, 16 * tk, c0, lane);
+                if ((t & nwm) == w) tile_update_16<66>(ct_T0, 16 * ti, 16 * tk, ct_T0, 16 * ti, ct_T0, 16 * tk, c0, lane);
         __syncthreads();
     }
     __syncthreads();

@@ -543,8 +543,8 @@ def main():
                                                "flops_per_point": N * (2 * d + 3), "counters": pmc_summary("predict_mean_mfma_kernel<")}
             ch_tf = extras["cholesky_gflops"] / 1e3
             extras["roofline_cholesky"] = {"bound": "mfma", "achieved": ch_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": ch_tf / FP64_PEAK_TFLOPS, "kernel": "chol_tasks_kernel (one launch, tile tasks with slab-wise hand-over; N^3/3 flops, assembly included in the time)",
-                                           "counters": pmc_summary("chol_tasks_kernel", "mean"),
+                                           "frac": ch_tf / FP64_PEAK_TFLOPS, "kernel": "chol_tasks8_kernel (one launch, tile tasks with slab-wise hand-over, eight waves per workgroup; N^3/3 flops, assembly included in the time)",
+                                           "counters": pmc_summary("chol_tasks8_kernel", "min"),
                                            "note": "N=2000 is latency-bound on the chain of 31 diagonal factorisations; the larger sizes are timed in extras.configs (C4: N=5000, C5: N=10000, chol_tasks8_kernel: 39 TFLOP/s; N=16000: 46 TFLOP/s; DESIGN.md par. 7, profiles/r03_cholesky_w8_vs_w4.txt)"}
             if args.config == "C3" and not shard:
                 t_cfg = time.perf_counter()

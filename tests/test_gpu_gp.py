@@ -610,7 +610,7 @@ def test_cholesky_task_queue(torch_gpu, monkeypatch, N, waves):
     update) from a queue and hand tiles over through versioned write-through stores.  Same factor as the launch-per-step path
     to rounding, K reproduced, a non-positive-definite matrix reported with LAPACK's pivot index, and a wait that runs out
     falls back to the step-by-step path with the same result.  Both kernels at every size: four waves per workgroup
-    (chol_tasks_kernel, the default below 40 block columns) and eight (chol_tasks8_kernel: four helper waves in the updates)."""
+    (chol_tasks_kernel, the reference) and eight (chol_tasks8_kernel, the default: four helper waves in the updates)."""
     from alabi_amd import HipGP
     from oracle.gp_oracle import OracleGP
     monkeypatch.setenv("ALABI_CHOL_W8", "1" if waves == 8 else "0")

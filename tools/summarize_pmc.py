@@ -1,7 +1,7 @@
 """Summarise rocprofv3 --pmc passes per kernel: python tools/summarize_pmc.py OUT.json DIR [DIR ...]
 
 Each DIR is the -d directory of one `rocprofv3 --pmc <COUNTERS> --output-format csv` run of the same command.  Per kernel and
-counter: calls, total, mean and max over the dispatches.  FETCH_SIZE and WRITE_SIZE are reported by the tool in KB
+counter: calls, total, mean, min and max over the dispatches.  FETCH_SIZE and WRITE_SIZE are reported by the tool in KB
 (MI355X_MICROARCH.md, HBM section; `mean_KB` / `max_KB` / `total_KB` are kept as aliases); the 2x correction for
 16-byte-per-lane streaming reads is applied by the reader (bench.py), not here.  SQ_* cycle counters count quad-cycles."""
 import csv, glob, json, os, sys
@@ -13,10 +13,11 @@ for d in dirs:
             k = row["Kernel_Name"].split("(")[0]
             c = row["Counter_Name"]
             v = float(row["Counter_Value"])
-            e = acc.setdefault(k, {}).setdefault(c, {"calls": 0, "total": 0.0, "max": 0.0})
+            e = acc.setdefault(k, {}).setdefault(c, {"calls": 0, "total": 0.0, "max": 0.0, "min": float("inf")})
             e["calls"] += 1
             e["total"] += v
             e["max"] = max(e["max"], v)
+            e["min"] = min(e["min"], v)
 for k in acc:
     for c, e in acc[k].items():
         e["mean"] = e["total"] / max(e["calls"], 1)
