@@ -74,7 +74,11 @@ __device__ inline double pivot_rsqrt(double piv) {
 // instructions per pivot -- 7.6 -> 8.0 us for the 64-pivot factorisation.  Data-dependent s_memrealtime stamps (ALABI_CHOL_PROF)
 // then put wave 0's slab recurrence at 1.1-1.2 us per 16 pivots = 172 cycles per pivot for ~31 instructions: a lone wave issues
 // one instruction per ~5.5 cycles and the recurrence is bound by that COUNT, as the round-2 text says; the four recurrences are
-// 4.6 of the factorisation's 7.5 us, the rank-16 updates between them, their barriers and the slab's LDS traffic the rest.)
+// 4.6 of the factorisation's 7.5 us, the rank-16 updates between them, their barriers and the slab's LDS traffic the rest.
+// (iii) EIGHT-column slabs in the task queue's diagonal factorisation (38 % fewer recurrence instructions: 8 x 156 instead of
+// 4 x 504; rank-8 tile updates on all waves, the tile column that holds the slab written back in its second half only):
+// the recurrences fell from 5.2 to 3.6 us and the seven instead of three slab boundaries (two barriers + an LDS round trip +
+// two dependent matrix-core instructions each, ~0.45 us) took it back -- N = 2000 0.527 vs 0.527 ms on one box.)
 __device__ inline void potrf_slab(double (&a)[16], int c0) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
