@@ -542,7 +542,8 @@ ens_group_kernel(GroupArgs p) {
         };
 #pragma unroll
         for (int r = 0; r < RT; ++r)
-            if (r < nreg) tile_products(xr[r], ar[r]);       // wave-uniform
+            tile_products(xr[r], ar[r]);                     // (tiles beyond nreg hold x = 0, alpha = 0: fma(0, 1, sum) = sum exactly --
+                                                             // unguarded, the RT tiles are straight-line code the compiler can interleave)
         for (int lt = 0; lt < nlds; ++lt) {
             const double* xbt = xb + (size_t)(wv * p.ltw + lt) * KS * 64 + lane;
             double bop[KS];
