@@ -151,6 +151,8 @@ int alabi_gp_destroy(alabi_gp* gp) {
     alabi::dev_cache_give(gp->winv, gp->winv_bytes);
     if (gp->small) (void)hipFree(gp->small);
     if (gp->pgrad) (void)hipFree(gp->pgrad);
+    if (gp->Xc) (void)hipFree(gp->Xc);
+    if (gp->ens_h) (void)hipFree(gp->ens_h);
     if (gp->mupart) (void)hipFree(gp->mupart);
     delete gp;
     return ALABI_OK;
@@ -571,6 +573,9 @@ int alabi_ens_last_path(alabi_ens* e, int* path) {
 
 // (inv_len, lo, hi) live in device memory; refreshed whenever the GP's hyper-parameters changed.
 static int sync_consts(alabi_ens* e, hipStream_t s) {
+    // squared exponential: the half-step kernels read the centred inputs and h = |x - c|^2 / 2 - ln|alpha| (ens_se_prepare; per GP,
+    // rebuilt when the inputs, y or the hyper-parameters moved) -- here, i.e. before any stream capture
+    if (e->gp->kf.type == 0 && e->gp->has_alpha) { const int st = ens_se_prepare(e->gp, s); if (st != ALABI_OK) return st; }
     if (e->consts_gen == e->gp->gen) return ALABI_OK;
     double host[5 * ALABI_MAX_DIM];
     for (int k = 0; k < ALABI_MAX_DIM; ++k) {
@@ -613,6 +618,7 @@ static HalfArgs base_args(alabi_ens* e, double* coords, double* logp) {
     alabi_gp* gp = e->gp;
     h.coords = coords; h.logp = logp; h.consts = e->consts;
     h.Xt = gp->Xt; h.alpha = gp->alpha; h.Npad = gp->Npad;
+    h.Xc = gp->Xc; h.ens_h = gp->ens_h; h.centre = gp->xa_centre;
     // the affine map of the log-probability folds into the amplitude and the mean: c (amp s + m) + e = (c amp) s + (c m + e)
     h.amp = e->lp_scale * std::exp(gp->log_amp); h.mean = std::fma(e->lp_scale, gp->mean, e->lp_shift); h.kf = gp->kf;
     h.W = e->W; h.d = e->d; h.n0 = (e->W + 1) / 2;

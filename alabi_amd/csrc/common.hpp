@@ -95,6 +95,11 @@ struct alabi_gp {
     size_t mupart_bytes = 0;
     double* pgrad = nullptr;  // scratch of the query-gradient path (v, |v|^2 partials, z parts)
     size_t pgrad_bytes = 0;
+    // ensemble kernels, squared exponential (ensemble.hip: se_pair_terms): the scaled training inputs relative to their mean
+    // (xa_centre) and h_n = |x_n - c|^2 / 2 - ln|alpha_n| with sign(alpha_n) in the lowest mantissa bit, rebuilt whenever `gen` moves
+    double* Xc = nullptr;     // [dim_bucket(d), Npad]
+    double* ens_h = nullptr;  // [Npad]
+    long long ens_h_gen = -1;
 };
 
 namespace alabi {
@@ -171,6 +176,7 @@ int launch_alpha(alabi_gp* gp, hipStream_t s);
 int launch_reductions(alabi_gp* gp, hipStream_t s);
 // gp_predict.hip
 int launch_predict_mean(alabi_gp* gp, const double* Xs, long long M, double* mu, hipStream_t s);
+int ens_se_prepare(alabi_gp* gp, hipStream_t s);     // Xc and ens_h of the current (inputs, alpha) for the squared-exponential half-step kernels
 int ensure_xa(alabi_gp* gp, hipStream_t s);           // augmented, centred rows Xa of the current factor (matrix-core predict-mean, group ensemble kernel)
 // Process-wide cache of the large scratch buffers (variance workspace, cached L^-1): the reference creates a new GP object
 // for every refit (gp_utils.py:233), and a 1-2 GiB hipMalloc per new handle costs tens of milliseconds.
@@ -203,6 +209,9 @@ struct HalfArgs {
     const double* consts;        // device [5][ALABI_MAX_DIM]: inv_len, lo, hi, prior mean, prior 1 / std
     const double* Xt;            // [D,Npad]
     const double* alpha;         // [Npad]
+    const double* Xc;            // [D,Npad] the scaled inputs relative to their mean   } squared exponential, half-step kernels
+    const double* ens_h;         // [Npad] |x - c|^2 / 2 - ln|alpha|, sign(alpha) in bit 0  } (se_pair_terms); see alabi_gp
+    const double* centre;        // [d] mean of the scaled training inputs
     double* chain;               // [nstore,E*W,d] or null
     double* chain_logp;          // [nstore,E*W] or null
     long long* n_accept;         // [E*W] or null

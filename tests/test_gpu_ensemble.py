@@ -311,3 +311,39 @@ def test_normal_prior_and_logp_affine_against_oracle(stream, monkeypatch):
         for k in (0, E - 1):
             refk = so.run_ensemble(p0e[k * W:(k + 1) * W], 40, lnp, seed=13, id0=k * W)
             assert np.max(np.abs(se.get_chain()[:, k * W:(k + 1) * W] - refk[0])) < 1e-7
+
+
+@pytest.mark.parametrize("stream", ["1", "0"])
+def test_half_step_kernels_inputs_far_from_origin(monkeypatch, stream):
+    """The squared-exponential half-step kernels (ens_stream_kernel / ens_half_kernel) form q.x - |x|^2/2 - |q|^2/2 instead of
+    -|x - q|^2/2 (se_pair_terms: one fma per point and coordinate, ln|alpha| folded into the resident norm); all coordinates are
+    taken relative to the mean of the training inputs, so inputs thousands of length scales from the origin keep their digits:
+    chain, log-probabilities and acceptance counts against the oracle (alabi/core.py:2319-2325 -> emcee stretch move)."""
+    from alabi_amd import EnsembleSampler, HipGP
+    from oracle.gp_oracle import OracleGP
+    from oracle import stretch_oracle as so
+    from oracle.stretch_oracle import box_lnprior_batch
+    monkeypatch.setenv("ALABI_ENS_STREAM", stream)
+    monkeypatch.setenv("ALABI_ENS_GROUP", "0")
+    X, y, h = make_problem(800, 4, 77, log_wn=-10.0, ell2=4.0)
+    off = np.array([4000.0, -2500.0, 1000.0, 8000.0])
+    Xo = X + off
+    g = HipGP(4, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(Xo)
+    o = OracleGP(4, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(Xo)
+    bounds = np.stack([off - 3.0, off + 3.0], axis=1)
+    p0 = off + np.random.RandomState(6).uniform(-2, 2, (32, 4))
+
+    def lnp(q):
+        lp = box_lnprior_batch(q, bounds)
+        out = np.full(len(q), -np.inf)
+        inside = np.isfinite(lp)
+        if inside.any():
+            out[inside] = o.predict(y, q[inside])
+        return out
+    s = EnsembleSampler(32, 4, g, y, bounds, seed=2)
+    s.run_mcmc(p0, 80)
+    assert s.last_path == ("stream" if stream == "1" else "launch-per-half-step")
+    chain_o, lp_o, nacc_o, _, _ = so.run_ensemble(p0, 80, lnp, seed=2)
+    assert np.max(np.abs(s.get_chain() - chain_o)) <= 1e-7 * 8000
+    assert np.max(np.abs(s.get_log_prob() - lp_o) / (np.abs(lp_o) + 1)) <= 1e-8
+    assert np.array_equal(s._naccept.cpu().numpy(), nacc_o)
