@@ -45,6 +45,12 @@ SIGNATURES = {
     "alabi_gp_nll": (_i, [_vp, _pd, _vp]),
     "alabi_gp_grad_log_likelihood": (_i, [_vp, _pd, _vp]),
     "alabi_gp_append": (_i, [_vp, _vp, _vp]),
+    "alabi_gp_batch_create": (_i, [_i, _i, _ll, C.POINTER(_vp)]),
+    "alabi_gp_batch_destroy": (_i, [_vp]),
+    "alabi_gp_batch_fit_predict": (_i, [_vp, _vp, _vp, _i, _i, _pd, _vp, _pll, _vp, _pll, _vp, _pd, _pi, _vp]),
+    "alabi_gp_batch_get_factor": (_i, [_vp, _i, _vp, _vp]),
+    "alabi_gp_batch_get_alpha": (_i, [_vp, _i, _vp, _vp]),
+    "alabi_gp_batch_timeouts": (_i, [_vp, _pi]),
     "alabi_gp_set_mean": (_i, [_vp, _d]),
     "alabi_gp_get_alpha": (_i, [_vp, _vp, _vp]),
     "alabi_gp_get_factor": (_i, [_vp, _vp, _vp]),
@@ -62,6 +68,7 @@ SIGNATURES = {
     "alabi_ens_accept": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "alabi_ens_set_stream": (_i, [_vp, _i]),
     "alabi_ens_last_path": (_i, [_vp, _pi]),
+    "alabi_ens_group_plan": (_i, [_vp, _pi]),
     "alabi_ens_lnprob": (_i, [_vp, _vp, _vp, _vp]),
     "alabi_ens_run": (_i, [_vp, _vp, _vp, _ll, _ll, _i, _d, _vp, _vp, _vp, _vp]),
     "alabi_ens_draw": (_i, [_vp, _ll, _i, _d, _vp]),

@@ -571,6 +571,12 @@ int alabi_ens_last_path(alabi_ens* e, int* path) {
     return ALABI_OK;
 }
 
+int alabi_ens_group_plan(alabi_ens* e, int* out) {
+    if (!e || !out) return ALABI_BAD_ARGUMENT;
+    for (int i = 0; i < 8; ++i) out[i] = e->group_plan[i];
+    return ALABI_OK;
+}
+
 // (inv_len, lo, hi) live in device memory; refreshed whenever the GP's hyper-parameters changed.
 static int sync_consts(alabi_ens* e, hipStream_t s) {
     // squared exponential: the half-step kernels read the centred inputs and h = |x - c|^2 / 2 - ln|alpha| (ens_se_prepare; per GP,

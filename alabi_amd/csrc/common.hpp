@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/alabi_hip.h"
 
@@ -158,7 +159,7 @@ struct alabi_ens {
     size_t part_words = 0;
     unsigned long long* cand = nullptr;  // [2 chunk_cap][E][n0][2 d + 4] candidate rows (proposal, old coordinates, logp, ln factors, prior)
     size_t cand_words = 0;
-    int group_q = 0, group_g = 0, group_ng = 0;   // blocking of the last group-kernel launch
+    int group_plan[8] = {0};  // blocking of the last group-kernel launch: Q, G, NG, RT, tpm, ltw, KS, LDS bytes (alabi_ens_group_plan)
 };
 
 namespace alabi {
@@ -171,6 +172,21 @@ int launch_kernel_matrix(const double* X1, int n1, const double* X2, int n2, int
 int launch_cholesky(alabi_gp* gp, hipStream_t s);
 int cholesky_tasks_prepare(alabi_gp* gp, hipStream_t s, int* ctl_ints);   // > 0: the task queue will run, its control words (to be zeroed by the assembly)
 int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched);
+int launch_cholesky_steps(double* L, int Npad, int* info, double* dinv, hipStream_t s);   // launch-per-step path on a bare matrix
+// batched task queue (gp_batch.hip): many independent matrices in one launch of chol_tasks8_batch_kernel
+struct CholTask;
+struct CholMat;
+struct CholBatchQueue {
+    std::vector<int> nbs;                       // key of the cached task list: block columns per matrix, lists, window
+    int nlists = 0, window = 0, B = 0;
+    CholTask* tasks = nullptr; size_t tasks_cap = 0; int ntasks = 0;
+    int* list_off = nullptr;                    // device [nlists + 1]
+    CholMat* mats = nullptr; size_t mats_cap = 0;
+    int* ctl = nullptr; size_t ctl_ints = 0, ctl_cap = 0;   // [32 q] list heads, [1] time-out flag, from [256] on: per matrix tile versions + slab counters
+};
+int chol_batch_prepare(CholBatchQueue& q, int B, const int* ld, double* const* A, double* const* dinv, int* const* info, hipStream_t s);
+int chol_batch_launch(CholBatchQueue& q, hipStream_t s);
+void chol_batch_free(CholBatchQueue& q);
 // gp_solve.hip
 int launch_alpha(alabi_gp* gp, hipStream_t s);
 int launch_reductions(alabi_gp* gp, hipStream_t s);

@@ -738,7 +738,8 @@ int launch_ens_group(alabi_ens* e, double* coords, double* logp, int K, int thin
     a.poll_delay = 6;                                        // ~0.16 us: measured optimum at C4 (5.13 vs 5.21 us per half step at 0, 5.5 at 20)
     a.amp = e->lp_scale * exp(gp->log_amp); a.mean = fma(e->lp_scale, gp->mean, e->lp_shift); a.kf = gp->kf;
     e->last_path = 3;
-    e->group_q = pl.Q; e->group_g = pl.G; e->group_ng = pl.NG;
+    { const int rec[8] = {pl.Q, pl.G, pl.NG, pl.RT, pl.tpm, pl.ltw, pl.KS, (int)pl.lds_bytes};
+      for (int i = 0; i < 8; ++i) e->group_plan[i] = rec[i]; }
     ALABI_GROUP_DISPATCH_KS(pl.KS, ALABI_GROUP_DISPATCH_Q(pl.Q, ALABI_DISPATCH_KERNEL(gp->kf.type,
         { st = group_launch<KS, Q, GENERIC>(a, pl, e->E, s); })));
     if (st != ALABI_OK) return st;

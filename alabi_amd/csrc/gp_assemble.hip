@@ -30,6 +30,7 @@ prepare_inputs_kernel(const double* __restrict__ X, int N, int Npad, int d, int 
 // difference-square-accumulate pairs -- 0.5 LDS reads per pair instead of 2 with one element per thread and step (round 3: the
 // kernel was bound by exactly those reads, 0.39 ms at N = 10000, d = 20, four times the time its 400 MB of writes take).  Sixteen
 // lanes store 128 contiguous bytes of a row.  Same operations per element in the same order: the same bits as before.
+// (assemble_tile in gp_device.hpp: shared with the batched assembly of gp_batch.hip, which must produce the same bits)
 __global__ void __launch_bounds__(256)
 assemble_lower_kernel(const double* __restrict__ Xt, int N, int Npad, int d, double amp, double wn, KernelFn kf,
                       double* __restrict__ K, int* __restrict__ zero, int zero_ints, int* __restrict__ info) {
@@ -45,45 +46,7 @@ assemble_lower_kernel(const double* __restrict__ Xt, int N, int Npad, int d, dou
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
     while (bi * (bi + 1) / 2 > t) --bi;
     int bj = t - bi * (bi + 1) / 2;
-    int tid = threadIdx.x;
-    for (int e = tid; e < d * 64; e += 256) {
-        int k = e >> 6, c = e & 63;
-        xi[k][c] = Xt[(size_t)k * Npad + bi * 64 + c];
-        xj[k][c] = Xt[(size_t)k * Npad + bj * 64 + c];
-    }
-    __syncthreads();
-    const int r0 = 4 * (tid >> 4), c0 = tid & 15;
-    double r2[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
-    for (int k = 0; k < d; ++k) {
-        double xa[4], xb[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) xa[a] = xi[k][r0 + a];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) xb[b] = xj[k][c0 + 16 * b];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const double df = xa[a] - xb[b];
-                r2[a][b] = fma(df, df, r2[a][b]);
-            }
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int gr = bi * 64 + r0 + a;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int gc = bj * 64 + c0 + 16 * b;
-            double v = amp * radial(r2[a][b], kf);
-            if (gr == gc) v += wn;
-            if (gr >= N || gc >= N) v = (gr == gc) ? 1.0 : 0.0;
-            K[(size_t)gr * Npad + gc] = v;
-        }
-    }
+    assemble_tile(xi, xj, Xt, N, Npad, d, amp, wn, kf, K, bi, bj);
 }
 
 // Rectangular kernel.get_value(x1, x2): both inputs raw [n,d] row-major.

@@ -533,6 +533,9 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
 //             4 UPDATE2 = UPDATE(i,j,..) and UPDATE(i+1,j,..) in one task (eight-wave kernel), 5 UPDATE4 = the 2 x 2 block of tiles
 //             (i,j), (i+1,j), (i,j+1), (i+1,j+1), i >= j + 1
 struct CholTask { int type, i, j, k; };
+// Batched queue (chol_tasks8_batch_kernel): bits 16.. of `type` say which matrix of the batch the task belongs to; the matrices are
+// independent, each with its own tile versions, slab counters, status word and reciprocal diagonal.
+struct CholMat { double* A; double* dinv; int* ver; int* sver; int* info; int ld, nb; };
 #define ALABI_CHOL_TASKS_MAX_NB 256   // default upper end of the one-launch task queue (N <= 16384); beyond: panels of 8 block columns
 #define ALABI_CHOL_W8_MIN_NB 16   // block columns from which the queue runs eight waves per workgroup (chol_tasks8_kernel)
 #define ALABI_CHOL_UPDATE4_MIN_NB 100 // block columns from which the far updates take 2 x 2 tiles per task (UPDATE4; below: UPDATE2)
@@ -725,15 +728,32 @@ __device__ inline void tile_put16(double (*T)[66], const TileRegs16<NT>& r, int 
 // barriers company, so the chain runs as fast as with four waves (two workgroups of four waves per CU were measured instead:
 // the grouped updates gained 27 %, but every recurrence that shared its SIMD with the other workgroup's matrix-core
 // instructions took 1.5-1.8x as long and the singles waited five times longer for their inputs; N = 10000 9.86 -> 9.59 ms only).
-template <int NT>
-__device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, int nb, const CholTask* __restrict__ tasks, int ntasks,
-                                                int* __restrict__ ctl, int* __restrict__ info, double* __restrict__ dinv, int spin_limit) {
+// BATCH: the queue holds the interleaved task lists of many independent matrices (the hyper-parameter search: candidates x folds,
+// gp_utils.py:511-700).  A task names its matrix (`mats`); the queue is cut into `nlists` lists, each with a head counter of its own
+// on a 128-byte line of its own (ctl[32 q]; one word saturates at ~88 draws per microsecond, MI355X_MICROARCH.md `dequeue`) and each
+// holding whole matrices, so a matrix's tiles stay in one XCD's L2: a workgroup starts on the list of its XCD and moves on to the
+// next list when one is exhausted.  Every list is a topological order of its own tasks and a workgroup only waits for tasks in
+// front of the one it drew, each of them drawn by a running workgroup: no deadlock, whatever the placement.
+template <int NT, bool BATCH>
+__device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_, int nb_, const CholTask* __restrict__ tasks, int ntasks,
+                                                int* __restrict__ ctl, int* __restrict__ info_, double* __restrict__ dinv_, int spin_limit,
+                                                const CholMat* __restrict__ mats, const int* __restrict__ list_off, int nlists) {
     double (*T0)[66] = ct_T0; double (*T1)[66] = ct_T1; double (*T2)[66] = ct_T2; double (*T3)[66] = ct_T3; double* di = ct_di;
-    __shared__ int task_s[6];
+    __shared__ int task_s[10];
+    // per task in a batch, fixed otherwise
+    double* A = A_; int ld = ld_, nb = nb_; int* info = info_; double* dinv = dinv_;
     int* head = ctl; int* err = ctl + 1; int* ver = ctl + 2;          // ver[i * nb + j]
     int* sver = ctl + 2 + nb * nb;                                    // sver[k]: slabs of L[k,k] published so far (0..4)
     int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
-    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(A, 0, (unsigned)ld * (unsigned)ld * 8u, 0x00020000);
+    __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(A, 0, (unsigned)ld * (unsigned)ld * 8u, 0x00020000);
+    if constexpr (BATCH) {
+        if (tid == 0) {                                               // task_s[6]: current list, [7]: lists found exhausted so far
+            int xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+            task_s[6] = (xcc & 15) % nlists;
+            task_s[7] = 0;
+        }
+    }
     // Panel solve of the tile in T1 against L[kk,kk], consumed slab by slab as its factorisation publishes them (sver[kk] =
     // slabs written through so far): wait (bounded), fetch the slab's 64 x 16 block and its reciprocals, solve the slab,
     // update the later slabs on the matrix cores.  false = a wait ran out (err is set; every thread returns).
@@ -835,14 +855,35 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, 
         }
         __syncthreads();                                              // the previous task is done with LDS and task_s
         if (tid == 0) {
-            const int idx = atomicAdd(head, 1);
+            int idx;
+            if constexpr (BATCH) {
+                int cur = task_s[6], gone = task_s[7];
+                for (;;) {
+                    if (gone >= nlists) { idx = ntasks; break; }
+                    const int beg = list_off[cur], len = list_off[cur + 1] - beg;
+                    idx = atomicAdd(ctl + 32 * cur, 1);
+                    if (idx < len) { idx += beg; break; }
+                    ++gone; cur = cur + 1 < nlists ? cur + 1 : 0;
+                }
+                task_s[6] = cur; task_s[7] = gone;
+            } else {
+                idx = atomicAdd(head, 1);
+            }
             task_s[4] = idx;
-            if (idx < ntasks) { const CholTask t = tasks[idx]; task_s[0] = t.type & 255; task_s[1] = t.i; task_s[2] = t.j; task_s[3] = t.k; task_s[5] = t.type >> 8; }
+            if (idx < ntasks) {
+                const CholTask t = tasks[idx];
+                task_s[0] = t.type & 255; task_s[1] = t.i; task_s[2] = t.j; task_s[3] = t.k; task_s[5] = (t.type >> 8) & 255; task_s[8] = t.type >> 16;
+            }
         }
         __syncthreads();
         if (task_s[4] >= ntasks) return;
         const int type = task_s[0], ti = task_s[1], tj = task_s[2], tk = task_s[3];
         const int tcnt = task_s[5] > 0 ? task_s[5] : 1;                 // UPDATE: block columns tk .. tk + tcnt - 1
+        if constexpr (BATCH) {                                        // this task's matrix (wave-uniform: scalar loads)
+            const CholMat cm = mats[__builtin_amdgcn_readfirstlane(task_s[8])];
+            A = cm.A; ld = cm.ld; nb = cm.nb; ver = cm.ver; sver = cm.sver; info = cm.info; dinv = cm.dinv;
+            arsrc = __builtin_amdgcn_make_buffer_rsrc(A, 0, (unsigned)ld * (unsigned)ld * 8u, 0x00020000);
+        }
 #ifdef ALABI_CHOL_PROF
         const long long pw0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1330,12 +1371,18 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A, int ld, 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 chol_tasks_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __restrict__ tasks, int ntasks, int* __restrict__ ctl,
                   int* __restrict__ info, double* __restrict__ dinv, int spin_limit) {
-    chol_tasks_body<256>(A, ld, nb, tasks, ntasks, ctl, info, dinv, spin_limit);
+    chol_tasks_body<256, false>(A, ld, nb, tasks, ntasks, ctl, info, dinv, spin_limit, nullptr, nullptr, 1);
 }
 __global__ void __launch_bounds__(512)
 chol_tasks8_kernel(double* __restrict__ A, int ld, int nb, const CholTask* __restrict__ tasks, int ntasks, int* __restrict__ ctl,
                    int* __restrict__ info, double* __restrict__ dinv, int spin_limit) {
-    chol_tasks_body<512>(A, ld, nb, tasks, ntasks, ctl, info, dinv, spin_limit);
+    chol_tasks_body<512, false>(A, ld, nb, tasks, ntasks, ctl, info, dinv, spin_limit, nullptr, nullptr, 1);
+}
+// ctl: [32 q] head of list q (q < nlists <= 8), [1] time-out flag
+__global__ void __launch_bounds__(512)
+chol_tasks8_batch_kernel(const CholMat* __restrict__ mats, const CholTask* __restrict__ tasks, int ntasks, const int* __restrict__ list_off,
+                         int nlists, int* __restrict__ ctl, int spin_limit) {
+    chol_tasks_body<512, true>(nullptr, 64, 1, tasks, ntasks, ctl, nullptr, nullptr, spin_limit, mats, list_off, nlists);
 }
 
 static int tiles_in_cols(int ntr, int tc0, int tc1) {
@@ -1528,10 +1575,11 @@ int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
     return ALABI_OK;
 }
 
-int launch_cholesky(alabi_gp* gp, hipStream_t s) {
-    const int ld = gp->Npad, nb = gp->Npad / 64;
-    // (gp->info was cleared by the assembly kernel, which always runs just before)
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, s, gp->L, ld, 0, gp->info, gp->dinv);
+// The launch-per-step factorisation of ONE [Npad, Npad] matrix (any owner: a GP handle, a slot of a batch workspace).
+int launch_cholesky_steps(double* L, int Npad, int* info, double* dinv, hipStream_t s) {
+    const int ld = Npad, nb = Npad / 64;
+    // (info was cleared by the assembly kernel, which always runs just before)
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, s, L, ld, 0, info, dinv);
     // Block columns per panel (0: rank-64 updates of the whole trailing matrix).  Measured on MI355X (tools/prof_cholesky.py):
     // the panel path wins from about N = 8000 on (N = 10000: 14.3 -> 11.3 ms, N = 16000: 49.6 -> 31.4 ms with panels of 8;
     // panels of 4: 11.8 / 33.0 ms); below that the extra launches per panel cost more than the trailing traffic they save
@@ -1541,8 +1589,8 @@ int launch_cholesky(alabi_gp* gp, hipStream_t s) {
     if (panel == 0) {
         for (int kb = 0; kb + 1 < nb; ++kb) {
             const int T = nb - kb - 1;
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(256), 0, s, gp->L, ld, kb, gp->dinv);
-            hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, s, gp->L, ld, kb, gp->info, gp->dinv, 0, T);   // + potrf of block kb+1
+            hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(256), 0, s, L, ld, kb, dinv);
+            hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, s, L, ld, kb, info, dinv, 0, T);   // + potrf of block kb+1
         }
         ALABI_LAUNCH_CHECK();
         return ALABI_OK;
@@ -1574,39 +1622,183 @@ int launch_cholesky(alabi_gp* gp, hipStream_t s) {
         for (int kb = p0; kb < pe; ++kb) {
             const int T = nb - kb - 1;
             if (T == 0) break;
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(256), 0, s, gp->L, ld, kb, gp->dinv);
+            hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(256), 0, s, L, ld, kb, dinv);
             const int jc = pe - kb - 1;
             if (jc > 0) {
                 int tiles = 0;
                 for (int tj = 0; tj < jc; ++tj) tiles += T - tj;
-                hipLaunchKernelGGL(syrk_update_kernel, dim3(tiles), dim3(256), 0, s, gp->L, ld, kb, gp->info, gp->dinv, jc, T);
+                hipLaunchKernelGGL(syrk_update_kernel, dim3(tiles), dim3(256), 0, s, L, ld, kb, info, dinv, jc, T);
             }
         }
         if (pe >= nb) break;
-        const int row0 = 64 * pe, ntr = (gp->Npad - row0 + 127) / 128, kp = 64 * (pe - p0);
+        const int row0 = 64 * pe, ntr = (Npad - row0 + 127) / 128, kp = 64 * (pe - p0);
         const int next_tc = (panel * 64) / 128;          // tile columns that make up the next panel
         const int tc_split = next_tc < ntr ? next_tc : ntr;
         if (lookahead) {
             // the rest of the PREVIOUS panel's update touched the tiles we are about to update: wait for it
             if (rest_pending) ALABI_HIP_CHECK(hipStreamWaitEvent(s, ev_rest[(pi + 1) & 1], 0));
             ALABI_HIP_CHECK(hipEventRecord(ev_panel[pi & 1], s));                       // panel pi is final
-            hipLaunchKernelGGL(syrk_panel_kernel<true>, dim3(tiles_in_cols(ntr, 0, tc_split)), dim3(256), 0, s, gp->L, ld, gp->Npad, 64 * p0, kp,
-                               row0, 0, tc_split, ntr, gp->info, gp->dinv);
+            hipLaunchKernelGGL(syrk_panel_kernel<true>, dim3(tiles_in_cols(ntr, 0, tc_split)), dim3(256), 0, s, L, ld, Npad, 64 * p0, kp,
+                               row0, 0, tc_split, ntr, info, dinv);
             if (tc_split < ntr) {
                 ALABI_HIP_CHECK(hipStreamWaitEvent(side, ev_panel[pi & 1], 0));
-                hipLaunchKernelGGL(syrk_panel_kernel<false>, dim3(tiles_in_cols(ntr, tc_split, ntr)), dim3(256), 0, side, gp->L, ld, gp->Npad,
-                                   64 * p0, kp, row0, tc_split, ntr, ntr, gp->info, (double*)nullptr);
+                hipLaunchKernelGGL(syrk_panel_kernel<false>, dim3(tiles_in_cols(ntr, tc_split, ntr)), dim3(256), 0, side, L, ld, Npad,
+                                   64 * p0, kp, row0, tc_split, ntr, ntr, info, (double*)nullptr);
                 ALABI_HIP_CHECK(hipEventRecord(ev_rest[pi & 1], side));
                 rest_pending = true;
             } else {
                 rest_pending = false;
             }
         } else {
-            hipLaunchKernelGGL(syrk_panel_kernel<true>, dim3(tiles_in_cols(ntr, 0, ntr)), dim3(256), 0, s, gp->L, ld, gp->Npad, 64 * p0, kp, row0,
-                               0, ntr, ntr, gp->info, gp->dinv);
+            hipLaunchKernelGGL(syrk_panel_kernel<true>, dim3(tiles_in_cols(ntr, 0, ntr)), dim3(256), 0, s, L, ld, Npad, 64 * p0, kp, row0,
+                               0, ntr, ntr, info, dinv);
         }
     }
     if (lookahead && rest_pending) ALABI_HIP_CHECK(hipStreamWaitEvent(s, ev_rest[(pi + 1) & 1], 0));
+    ALABI_LAUNCH_CHECK();
+    return ALABI_OK;
+}
+
+int launch_cholesky(alabi_gp* gp, hipStream_t s) { return launch_cholesky_steps(gp->L, gp->Npad, gp->info, gp->dinv, s); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched task queue: B independent matrices in ONE launch (gp_batch.hip: the folds x candidates of the hyper-parameter search).
+// A single matrix of 16..40 block columns leaves the chip idle -- its time is the chain of nb CHAIN tasks, ~17 us each, with 8 %
+// matrix-core duty at N = 2000 -- so the task lists of many matrices are interleaved: the chains of different matrices run side by
+// side on different workgroups and the bulk updates of one fill the gaps of another.
+//   * matrix b goes to list b % nlists (one list per XCD: its tiles stay in that XCD's L2, its own head counter);
+//   * inside a list the matrices advance in SLOTS: slot t holds step t - start_m of every matrix m of the list that is active,
+//     start_m = floor(rank_m * stagger) -- with stagger = steps / P about P matrices per list are in flight at any time, in
+//     different phases (the wide early steps of one beside the narrow late steps of another), and the working set stays
+//     ~ P * nlists lower triangles instead of all B;
+//   * within a slot the matrices closest to their end come first (their steps are short and chain-bound).
+// Each matrix keeps the order of its own list, so every list remains a topological order.
+static int chol_batch_build(const std::vector<int>& nbs, int nlists, int window, std::vector<CholTask>& out, std::vector<int>& list_off) {
+    std::map<int, std::pair<std::vector<CholTask>, std::vector<int>>> per_nb;       // nb -> (tasks, first task of every step)
+    for (int nb : nbs) {
+        if (per_nb.count(nb)) continue;
+        int gk, near;
+        chol_task_shape(nb, &gk, &near);
+        auto& e = per_nb[nb];
+        chol_build_tasks(nb, gk, near, chol_tasks_two(nb, gk), e.first);
+        for (size_t q = 0; q < e.first.size(); ++q)
+            if ((e.first[q].type & 255) == 0) e.second.push_back((int)q);            // a CHAIN task opens a step
+        e.second.push_back((int)e.first.size());
+    }
+    out.clear();
+    list_off.assign(nlists + 1, 0);
+    for (int q = 0; q < nlists; ++q) {
+        list_off[q] = (int)out.size();
+        std::vector<int> mem;                                                        // matrices of this list
+        for (int b = q; b < (int)nbs.size(); b += nlists) mem.push_back(b);
+        if (mem.empty()) continue;
+        std::vector<int> start(mem.size());
+        int last_slot = 0;
+        for (size_t r = 0; r < mem.size(); ++r) {
+            const int steps = nbs[mem[r]];
+            const double stagger = window > 0 ? (double)steps / window : 0.0;
+            start[r] = (int)(r * stagger);
+            if (start[r] + steps > last_slot) last_slot = start[r] + steps;
+        }
+        for (int t = 0; t < last_slot; ++t)
+            for (size_t r = 0; r < mem.size(); ++r) {                               // lower rank = started earlier = closer to its end
+                const int b = mem[r], st = t - start[r];
+                if (st < 0 || st >= nbs[b]) continue;
+                const auto& e = per_nb[nbs[b]];
+                for (int x = e.second[st]; x < e.second[st + 1]; ++x) {
+                    CholTask c = e.first[x];
+                    c.type |= b << 16;
+                    out.push_back(c);
+                }
+            }
+    }
+    list_off[nlists] = (int)out.size();
+    return (int)out.size();
+}
+
+extern "C" int alabi_debug_chol_batch_tasks(int B, const int* nbs, int nlists, int window, int* out, int cap, int* list_off_out) {
+    std::vector<int> v(nbs, nbs + B), lo;
+    std::vector<CholTask> t;
+    chol_batch_build(v, nlists, window, t, lo);
+    if (out)
+        for (size_t q = 0; q < t.size() && (int)q < cap; ++q) { out[4 * q] = t[q].type; out[4 * q + 1] = t[q].i; out[4 * q + 2] = t[q].j; out[4 * q + 3] = t[q].k; }
+    if (list_off_out) for (int q = 0; q <= nlists; ++q) list_off_out[q] = lo[q];
+    return (int)t.size();
+}
+
+void chol_batch_free(CholBatchQueue& q) {
+    if (q.tasks) (void)hipFree(q.tasks);
+    if (q.list_off) (void)hipFree(q.list_off);
+    if (q.mats) (void)hipFree(q.mats);
+    if (q.ctl) (void)hipFree(q.ctl);
+    q = CholBatchQueue{};
+}
+
+// Queue B matrices (slot b: A[b] [ld[b], ld[b]] row-major with ld a multiple of 64, dinv[b] [ld[b]], info[b] [1], all device memory):
+// builds (or reuses) the interleaved task list, uploads the matrix table, clears the control words -- everything on `s`.
+int chol_batch_prepare(CholBatchQueue& q, int B, const int* ld, double* const* A, double* const* dinv, int* const* info, hipStream_t s) {
+    if (B <= 0 || B >= 32768) return ALABI_BAD_ARGUMENT;
+    int nlists = 8, window = 3;
+    if (const char* e = getenv("ALABI_BATCH_LISTS")) { const int v = atoi(e); if (v >= 1 && v <= 8) nlists = v; }
+    if (const char* e = getenv("ALABI_BATCH_WINDOW")) { const int v = atoi(e); if (v >= 0 && v <= 4096) window = v; }
+    if (nlists > B) nlists = B;
+    std::vector<int> nbs(B);
+    size_t ver_ints = 0;
+    for (int b = 0; b < B; ++b) {
+        if (ld[b] <= 0 || ld[b] % 64 != 0 || ld[b] / 64 > 256) return ALABI_BAD_ARGUMENT;
+        nbs[b] = ld[b] / 64;
+        ver_ints += (size_t)nbs[b] * nbs[b] + nbs[b];
+    }
+    if (!(q.tasks && q.nbs == nbs && q.nlists == nlists && q.window == window)) {
+        std::vector<CholTask> t;
+        std::vector<int> lo;
+        chol_batch_build(nbs, nlists, window, t, lo);
+        if (t.size() > q.tasks_cap) {
+            if (q.tasks) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(q.tasks); q.tasks = nullptr; q.tasks_cap = 0; }
+            ALABI_HIP_CHECK(hipMalloc(&q.tasks, t.size() * sizeof(CholTask)));
+            q.tasks_cap = t.size();
+        }
+        if (!q.list_off) ALABI_HIP_CHECK(hipMalloc(&q.list_off, 9 * sizeof(int)));
+        ALABI_HIP_CHECK(hipStreamSynchronize(s));                         // a launch still reading the previous list
+        ALABI_HIP_CHECK(hipMemcpy(q.tasks, t.data(), t.size() * sizeof(CholTask), hipMemcpyHostToDevice));
+        ALABI_HIP_CHECK(hipMemcpy(q.list_off, lo.data(), (nlists + 1) * sizeof(int), hipMemcpyHostToDevice));
+        q.ntasks = (int)t.size(); q.nbs = nbs; q.nlists = nlists; q.window = window;
+    }
+    if ((size_t)B > q.mats_cap) {
+        if (q.mats) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(q.mats); q.mats = nullptr; }
+        ALABI_HIP_CHECK(hipMalloc(&q.mats, (size_t)B * sizeof(CholMat)));
+        q.mats_cap = B;
+    }
+    const size_t ctl_ints = 256 + ver_ints;
+    if (ctl_ints > q.ctl_cap) {
+        if (q.ctl) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(q.ctl); q.ctl = nullptr; }
+        ALABI_HIP_CHECK(hipMalloc(&q.ctl, ctl_ints * sizeof(int)));
+        q.ctl_cap = ctl_ints;
+    }
+    q.ctl_ints = ctl_ints;
+    std::vector<CholMat> hm(B);
+    size_t off = 256;
+    for (int b = 0; b < B; ++b) {
+        hm[b].A = A[b]; hm[b].dinv = dinv[b]; hm[b].info = info[b]; hm[b].ld = ld[b]; hm[b].nb = nbs[b];
+        hm[b].ver = q.ctl + off; hm[b].sver = q.ctl + off + (size_t)nbs[b] * nbs[b];
+        off += (size_t)nbs[b] * nbs[b] + nbs[b];
+    }
+    ALABI_HIP_CHECK(hipMemcpyAsync(q.mats, hm.data(), (size_t)B * sizeof(CholMat), hipMemcpyHostToDevice, s));
+    ALABI_HIP_CHECK(hipStreamSynchronize(s));                             // `hm` is a local
+    ALABI_HIP_CHECK(hipMemsetAsync(q.ctl, 0, ctl_ints * sizeof(int), s));
+    q.B = B;
+    return ALABI_OK;
+}
+
+// One launch of the batched queue; the time-out flag is q.ctl[1] (read it after synchronising: non-zero = undefined matrices).
+int chol_batch_launch(CholBatchQueue& q, hipStream_t s) {
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = q.ntasks < n_cu ? q.ntasks : n_cu;
+    int spin = 1 << 18;
+    if (const char* e2 = getenv("ALABI_CHOL_SPIN_LIMIT")) { const int v = atoi(e2); if (v > 0) spin = v; }
+    hipLaunchKernelGGL(chol_tasks8_batch_kernel, dim3(grid), dim3(512), 0, s, q.mats, q.tasks, q.ntasks, q.list_off, q.nlists, q.ctl, spin);
     ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }

@@ -155,6 +155,51 @@ __device__ inline double radial(double r2, KernelFn kf) {
     return exp(-kf.alpha * log1p(0.5 * r2 / kf.alpha));
 }
 
+// One 64 x 64 tile (bi >= bj) of K = amp f(r2) + wn I from the scaled, transposed inputs Xt [d][Npad], identity in the padding;
+// 256 threads, each a 4 x 4 micro-tile (gp_assemble.hip).  xi / xj: the caller's LDS staging arrays.
+__device__ inline void assemble_tile(double (*xi)[64], double (*xj)[64], const double* __restrict__ Xt, int N, int Npad, int d,
+                                     double amp, double wn, KernelFn kf, double* __restrict__ K, int bi, int bj) {
+    const int tid = threadIdx.x;
+    for (int e = tid; e < d * 64; e += 256) {
+        int k = e >> 6, c = e & 63;
+        xi[k][c] = Xt[(size_t)k * Npad + bi * 64 + c];
+        xj[k][c] = Xt[(size_t)k * Npad + bj * 64 + c];
+    }
+    __syncthreads();
+    const int r0 = 4 * (tid >> 4), c0 = tid & 15;
+    double r2[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+    for (int k = 0; k < d; ++k) {
+        double xa[4], xb[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xa[a] = xi[k][r0 + a];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) xb[b] = xj[k][c0 + 16 * b];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double df = xa[a] - xb[b];
+                r2[a][b] = fma(df, df, r2[a][b]);
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int gr = bi * 64 + r0 + a;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int gc = bj * 64 + c0 + 16 * b;
+            double v = amp * radial(r2[a][b], kf);
+            if (gr == gc) v += wn;
+            if (gr >= N || gc >= N) v = (gr == gc) ? 1.0 : 0.0;
+            K[(size_t)gr * Npad + gc] = v;
+        }
+    }
+}
+
 // Run `...` with `constexpr bool GENERIC` = (kernel family != squared exponential).
 #define ALABI_DISPATCH_KERNEL(KTYPE, ...)                         \
     if ((KTYPE) == 0) { constexpr bool GENERIC = false; __VA_ARGS__; } \

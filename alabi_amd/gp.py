@@ -241,6 +241,27 @@ class HipGP:
         self._y_set = False
         self._alpha_host = None
 
+    def full_hyper(self, vector=None, include_frozen=False):
+        """[mean, log white noise, log amplitude, log alpha, log M_1..d] that ``set_parameter_vector(vector)`` would give (the
+        current values for ``vector=None``) WITHOUT touching this object: one row of HipGPBatch.fit_predict's table."""
+        mean, wn, amp, la, lm = self.mean_value, self.white_noise_value, self.log_constant, self.log_alpha, self.log_M
+        if vector is not None:
+            p = np.asarray(vector, dtype=np.float64).ravel()
+            n_expected = len(self.get_parameter_names(include_frozen))
+            if p.size != n_expected:
+                raise ValueError(f"dimension mismatch: expected {n_expected} parameters, got {p.size}")
+            i = 0
+            if self.fit_mean or include_frozen:
+                mean = float(p[i]); i += 1
+            if self.fit_white_noise or include_frozen:
+                wn = float(p[i]); i += 1
+            if getattr(self, "fit_amp", True):
+                amp = float(p[i]); i += 1
+            if self.kernel_name == "RationalQuadraticKernel":
+                la = float(p[i]); i += 1
+            lm = p[i:i + self.ndim]
+        return np.concatenate([[mean, wn, amp, la], np.asarray(lm, dtype=np.float64)])
+
     def __len__(self):
         return len(self.get_parameter_names())
 

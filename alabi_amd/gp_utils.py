@@ -5,7 +5,8 @@ Mirrors the parts of alabi/gp_utils.py that the hot path's callers need:
 ``regularization_term`` / ``regularization_gradient`` (gp_utils.py:30-108, values pinned by
 tests/golden), and the staged random-search k-fold cross-validation
 ``optimize_gp_kfold_cv`` (gp_utils.py:511-637, :640-1231, :1234-1367).  Every factorisation,
-likelihood and held-out prediction runs in the HIP library (one ``gp.compute`` per fold).
+likelihood and held-out prediction runs in the HIP library: all (candidate, fold) jobs of a search
+stage in ONE batched call (alabi_gp_batch_fit_predict, gp_batch.py).
 """
 from __future__ import annotations
 
@@ -15,7 +16,8 @@ import numpy as np
 
 from .gp import HipGP
 
-__all__ = ["configure_gp", "regularization_term", "regularization_gradient", "optimize_gp_kfold_cv"]
+__all__ = ["configure_gp", "regularization_term", "regularization_gradient", "optimize_gp_kfold_cv", "cv_fold_scores",
+           "kfold_splits", "weighted_mse_by_probability"]
 
 
 def regularization_term(hparams, lengthscale_indices, amp_0=1.0, mu_0=1.0, sigma_0=2.0):
@@ -68,7 +70,29 @@ def configure_gp(theta, y, kernel, fit_amp=True, fit_mean=True, fit_white_noise=
     return gp
 
 
-def _score(y_val, y_pred, scoring):
+def weighted_mse_by_probability(y_true, y_pred, weight_method="exponential", temperature=1.0):
+    """MSE with larger weights on the points of higher log-likelihood (gp_utils.py:449-508; values pinned by
+    tests/golden/reference_cv_vectors.npz): weights exp(y/T), y - min(y) + 1e-6, softmax(y/T) or the rank, scaled to mean 1."""
+    y_true = np.asarray(y_true)
+    y_pred = np.asarray(y_pred)
+    if weight_method == "exponential":
+        w = np.exp(y_true / temperature)
+    elif weight_method == "linear":
+        w = y_true - np.min(y_true) + 1e-6
+    elif weight_method == "softmax":
+        w = np.exp(y_true / temperature)
+        w = w / np.sum(w) * len(w)
+    elif weight_method == "rank":
+        w = np.argsort(np.argsort(y_true)) + 1
+    else:
+        raise ValueError(f"Unknown weight_method: {weight_method}")
+    w = w / np.mean(w)
+    return np.average((y_true - y_pred) ** 2, weights=w)
+
+
+def _score(y_val, y_pred, scoring, weighted_mse_method="exponential", weighted_mse_factor=1.0):
+    """One fold's score, lower is better (gp_utils.py:603-619: sklearn's mean_squared_error / mean_absolute_error / -r2_score,
+    or weighted_mse_by_probability)."""
     if scoring == "mse":
         return float(np.mean((y_val - y_pred) ** 2))
     if scoring == "mae":
@@ -77,32 +101,15 @@ def _score(y_val, y_pred, scoring):
         ss_res = np.sum((y_val - y_pred) ** 2)
         ss_tot = np.sum((y_val - np.mean(y_val)) ** 2)
         return float(-(1.0 - ss_res / ss_tot))
+    if scoring == "weighted_mse":
+        return float(weighted_mse_by_probability(y_val, y_pred, weight_method=weighted_mse_method, temperature=weighted_mse_factor))
     raise ValueError(f"Unsupported scoring method: {scoring}")
-
-
-def _fold_score(gp_fold, hyperparams, theta_dev, y_dev, _y, train_dev, val_dev, val, inv, scoring, stream):
-    """One fold: factorise on `train`, predict `val` (gp_utils.py:568-600) -- one library call on its own HIP stream; the
-    training subset is gathered on the device from the resident full set."""
-    import torch
-    try:
-        with torch.cuda.stream(stream):
-            gp_fold.set_parameter_vector(hyperparams)
-            ll, mu = gp_fold.fit_predict_device(theta_dev.index_select(0, train_dev), y_dev.index_select(0, train_dev),
-                                                theta_dev.index_select(0, val_dev))
-            if not np.isfinite(ll):
-                raise ValueError("GP log-likelihood is invalid")
-            _y_pred = mu.cpu().numpy()
-        if not np.all(np.isfinite(_y_pred)):
-            raise ValueError("GP predictions contain NaN or Inf values")
-        return _score(inv(_y[val]), inv(_y_pred), scoring)
-    except Exception:  # noqa: BLE001
-        return np.inf
 
 
 def _inverse_map(y_scaler):
     """y_scaler.inverse_transform as a plain function of a 1-D array.  An affine scaler (no_scaler, StandardScaler,
     MinMaxScaler, ...) is recognised by probing and replaced by a * y + b: sklearn's validation costs 50 us per call, and a
-    CV search would make 1750 of them under the GIL."""
+    CV search makes 1750 of them."""
     probe = np.array([[-1.7], [0.0], [0.9], [3.3]])
     try:
         out = np.asarray(y_scaler.inverse_transform(probe), dtype=np.float64).ravel()
@@ -116,103 +123,89 @@ def _inverse_map(y_scaler):
     return lambda v: y_scaler.inverse_transform(np.asarray(v).reshape(-1, 1)).flatten()
 
 
-class _FoldWorkers:
-    """T GP copies, T HIP streams and T host threads working through (candidate, fold) jobs: the jobs are independent, each
-    factorisation fills only part of the chip and every call blocks on a read-back, so they are issued concurrently (the
-    reference maps them over a process pool, gp_utils.py:640-700).  ctypes releases the GIL during the library calls;
-    distinct handles are thread-safe.  T = ALABI_CV_THREADS (default k, at most 12; more threads only contend for the GIL); 1 runs the jobs one after the other."""
-
-    def __init__(self, gp, k_folds):
-        import os
-        import queue
-        import torch
-        from concurrent.futures import ThreadPoolExecutor
-        self.k = k_folds
-        self.nthreads = max(1, min(12, int(os.environ.get("ALABI_CV_THREADS", k_folds))))
-        self.free = queue.SimpleQueue()
-        for _ in range(self.nthreads):
-            self.free.put((copy.deepcopy(gp), torch.cuda.Stream() if self.nthreads > 1 else torch.cuda.current_stream()))
-        self.pool = ThreadPoolExecutor(max_workers=self.nthreads) if self.nthreads > 1 else None
-
-    def _job(self, args):
-        res = self.free.get()
-        try:
-            return _fold_score(res[0], *args, res[1])
-        finally:
-            self.free.put(res)
-
-    def run_many(self, jobs):
-        """jobs: the argument tuples of _fold_score after the GP and before the stream -> scores in the same order"""
-        import torch
-        if self.pool is None:
-            return [self._job(j) for j in jobs]
-        torch.cuda.current_stream().synchronize()
-        return list(self.pool.map(self._job, jobs))
-
-    def close(self):
-        if self.pool is not None:
-            self.pool.shutdown(wait=True)
+def kfold_splits(n, k_folds, rng):
+    """The validation sets of sklearn's KFold(n_splits=k, shuffle=True) on `rng`'s stream (gp_utils.py:538): one shuffle of
+    arange(n), cut into k consecutive pieces, the first n % k one longer (pinned: tests/golden/reference_cv_vectors.npz)."""
+    return np.array_split(rng.permutation(n), k_folds)
 
 
-def _fold_jobs(hyperparams, _theta, _y, folds, y_scaler, scoring, inv=None, dev=None):
-    """dev = (theta_dev, y_dev): the full training set resident on the device (uploaded once per search)"""
-    import torch
+def cv_fold_scores(gp, candidates, fold_sets, _theta, _y, y_scaler, scoring="mse", weighted_mse_method="exponential",
+                   weighted_mse_factor=1.0, batch=None, dev=None, inv=None):
+    """Fold scores of several hyper-parameter vectors in ONE batched library call (gp_utils.py:511-637 per candidate):
+    ``fold_sets[c]`` = the k validation index sets of candidate c; per fold the GP is factorised on the other rows with
+    ``candidates[c]``, its log-likelihood checked, the held-out rows predicted, and the score taken on UN-scaled values
+    (``y_scaler.inverse_transform``).  Returns [len(candidates)][k] floats, np.inf = failed fold (not positive definite,
+    non-finite likelihood or predictions, as the reference's per-fold try/except)."""
     from .gp import _to_dev
-    k_folds = len(folds)
-    inv = _inverse_map(y_scaler) if inv is None else inv
-    if dev is None:
-        dev = (_to_dev(np.ascontiguousarray(_theta, dtype=np.float64), 2), _to_dev(np.ascontiguousarray(_y, dtype=np.float64)))
-    jobs = []
-    for k in range(k_folds):
-        val = np.sort(folds[k])
-        train = np.sort(np.concatenate([folds[j] for j in range(k_folds) if j != k]))
-        idx = torch.as_tensor(np.concatenate([train, val]), device=dev[0].device)
-        jobs.append((hyperparams, dev[0], dev[1], _y, idx[:len(train)], idx[len(train):], val, inv, scoring))
-    return jobs
+    from .gp_batch import HipGPBatch
+    own = batch is None
+    if own:
+        batch = HipGPBatch(gp.ndim, gp.kernel_name)
+    try:
+        inv = _inverse_map(y_scaler) if inv is None else inv
+        if dev is None:
+            dev = (_to_dev(np.ascontiguousarray(_theta, dtype=np.float64), 2), _to_dev(np.ascontiguousarray(_y, dtype=np.float64)))
+        hyper, train, val, owner = [], [], [], []
+        for c, (hp, folds) in enumerate(zip(candidates, fold_sets)):
+            row = gp.full_hyper(hp)
+            for k in range(len(folds)):
+                v = np.sort(np.asarray(folds[k]))
+                t = np.sort(np.concatenate([folds[q] for q in range(len(folds)) if q != k]))
+                hyper.append(row); train.append(t); val.append(v); owner.append(c)
+        out = [[np.inf] * len(f) for f in fold_sets]
+        if not hyper:
+            return out
+        ll, status, mu, off = batch.fit_predict(dev[0], dev[1], np.array(hyper), train, val)
+        mu_host = mu.cpu().numpy() if mu is not None else np.zeros(0)
+        pos = [0] * len(fold_sets)
+        for b, c in enumerate(owner):
+            k = pos[c]; pos[c] += 1
+            if status[b] != 0 or not np.isfinite(ll[b]):
+                continue
+            pred = mu_host[off[b]:off[b + 1]]
+            if pred.size == 0 or not np.all(np.isfinite(pred)):
+                continue
+            try:
+                sc = _score(inv(_y[val[b]]), inv(pred), scoring, weighted_mse_method, weighted_mse_factor)
+            except Exception:  # noqa: BLE001
+                continue
+            out[c][k] = sc if np.isfinite(sc) or sc == np.inf else np.inf
+        return out
+    finally:
+        if own:
+            batch.close()
 
 
-def _evaluate_candidate(hyperparams, gp, _theta, _y, y_scaler, k_folds, scoring, rng, workers=None):
+def _evaluate_candidate(hyperparams, gp, _theta, _y, y_scaler, k_folds, scoring, rng, **kw):
     """Fold scores of one hyper-parameter vector (gp_utils.py:511-637); np.inf marks a failed fold."""
     if not np.all(np.isfinite(hyperparams)):
         return None
-    n = len(_theta)
-    perm = rng.permutation(n)                      # KFold(shuffle=True, random_state=None)
-    folds = np.array_split(perm, k_folds)
-    own = workers is None
-    if own:
-        workers = _FoldWorkers(gp, k_folds)
-    try:
-        return workers.run_many(_fold_jobs(hyperparams, _theta, _y, folds, y_scaler, scoring))
-    finally:
-        if own:
-            workers.close()
+    return cv_fold_scores(gp, [hyperparams], [kfold_splits(len(_theta), k_folds, rng)], _theta, _y, y_scaler, scoring, **kw)[0]
 
 
-def _mean_scores(cands, gp, _theta, _y, y_scaler, k_folds, scoring, rng):
+def _mean_scores(cands, gp, _theta, _y, y_scaler, k_folds, scoring, rng, batch=None, ranks=None, **kw):
     """Mean fold score per candidate.  The fold permutations are drawn first, in candidate order (the random stream is the
-    same as when the candidates are evaluated one after the other), then all (candidate, fold) jobs go to the workers."""
+    same as when the candidates are evaluated one after the other), then ALL (candidate, fold) jobs of the stage go to one
+    batched call.  ``ranks=(rank, world)``: this process evaluates candidates rank, rank + world, ... only (the caller
+    combines the partial score vectors: np.inf elsewhere)."""
+    from .gp import _to_dev
     out = np.full(len(cands), np.inf)
     n = len(_theta)
     inv = _inverse_map(y_scaler)
-    from .gp import _to_dev
     dev = (_to_dev(np.ascontiguousarray(_theta, dtype=np.float64), 2), _to_dev(np.ascontiguousarray(_y, dtype=np.float64)))
-    jobs, owner = [], []
+    sel, fold_sets = [], []
     for i, hp in enumerate(cands):
         if not np.all(np.isfinite(hp)):
             continue
-        folds = np.array_split(rng.permutation(n), k_folds)
-        jb = _fold_jobs(hp, _theta, _y, folds, y_scaler, scoring, inv, dev)
-        jobs.extend(jb); owner.extend([i] * len(jb))
-    if not jobs:
+        folds = kfold_splits(n, k_folds, rng)                 # drawn for EVERY finite candidate: the stream does not depend on `ranks`
+        if ranks is not None and i % ranks[1] != ranks[0]:
+            continue
+        sel.append(i); fold_sets.append(folds)
+    if not sel:
         return out
-    workers = _FoldWorkers(gp, k_folds)
-    try:
-        scores = np.asarray(workers.run_many(jobs), dtype=np.float64)
-    finally:
-        workers.close()
-    owner = np.asarray(owner)
-    for i in np.unique(owner):
-        s = scores[owner == i]
+    scores = cv_fold_scores(gp, [cands[i] for i in sel], fold_sets, _theta, _y, y_scaler, scoring, batch=batch, dev=dev, inv=inv, **kw)
+    for i, s in zip(sel, scores):
+        s = np.asarray(s, dtype=np.float64)
         ok = s[np.isfinite(s)]
         if len(ok):
             out[i] = np.mean(ok)
@@ -238,7 +231,8 @@ def _perturbed(best, n_candidates, width, rng):
 
 def optimize_gp_kfold_cv(gp, _theta, _y, hyperparameter_candidates, y_scaler, k_folds=5, scoring="mse", pool=None,
                          stage2_candidates=None, stage2_width=0.5, stage3_candidates=None, stage3_width=0.2,
-                         weighted_mse_method="exponential", weighted_mse_factor=1.0, verbose=True, random_state=None):
+                         weighted_mse_method="exponential", weighted_mse_factor=1.0, verbose=True, random_state=None,
+                         ranks=None, reduce_scores=None):
     """Pick the candidate with the lowest mean k-fold validation score, refine around it in up to two
     further random-search stages, set it on ``gp`` and factorise on all the data.  Returns ``gp`` or
     None when every candidate failed (gp_utils.py:640-1231)."""
@@ -253,7 +247,22 @@ def optimize_gp_kfold_cv(gp, _theta, _y, hyperparameter_candidates, y_scaler, k_
     if k_folds < 2:
         raise ValueError(f"k_folds must be >= 2, got {k_folds}")
     rng = np.random.RandomState(random_state)
-    scores = _mean_scores(cands, gp, _theta, _y, y_scaler, k_folds, scoring, rng)
+    from .gp_batch import HipGPBatch
+    batch = HipGPBatch(gp.ndim, gp.kernel_name)
+    kw = dict(batch=batch, weighted_mse_method=weighted_mse_method, weighted_mse_factor=weighted_mse_factor, ranks=ranks)
+    try:
+        return _optimize_gp_kfold_cv(gp, _theta, _y, cands, y_scaler, k_folds, scoring, stage2_candidates, stage2_width,
+                                     stage3_candidates, stage3_width, verbose, rng, kw, reduce_scores)
+    finally:
+        batch.close()
+
+
+def _optimize_gp_kfold_cv(gp, _theta, _y, cands, y_scaler, k_folds, scoring, stage2_candidates, stage2_width, stage3_candidates,
+                          stage3_width, verbose, rng, kw, reduce_scores):
+    def _mean_scores_all(c):
+        s = _mean_scores(c, gp, _theta, _y, y_scaler, k_folds, scoring, rng, **kw)
+        return s if reduce_scores is None else reduce_scores(s)
+    scores = _mean_scores_all(cands)
     if np.all(np.isinf(scores)):
         return None
     best = cands[int(np.argmin(scores))]
@@ -267,7 +276,7 @@ def optimize_gp_kfold_cv(gp, _theta, _y, hyperparameter_candidates, y_scaler, k_
             stages.append((stage3_candidates, stage3_width))
     for k, (ncand, width) in enumerate(stages, start=2):
         c = _perturbed(best, int(ncand), width, rng)
-        s = _mean_scores(c, gp, _theta, _y, y_scaler, k_folds, scoring, rng)
+        s = _mean_scores_all(c)
         if not np.all(np.isinf(s)) and np.min(s) < best_score:
             best, best_score = c[int(np.argmin(s))], float(np.min(s))
         if verbose:

@@ -310,6 +310,11 @@ class EnsembleSampler:
         _lib.lib().alabi_ens_last_path(self._ens, C.byref(path))
         self.last_path = {1: "stream", 3: "group"}.get(path.value, "launch-per-half-step")
         self.last_stream_kernel = {1: "ens_stream_kernel", 3: "ens_group_kernel"}.get(path.value)
+        self.group_plan = None
+        if path.value == 3:                                   # which instantiation of ens_group_kernel ran (tests pin it)
+            plan = (C.c_int * 8)()
+            _lib.lib().alabi_ens_group_plan(self._ens, plan)
+            self.group_plan = dict(zip(("Q", "G", "NG", "RT", "tpm", "ltw", "KS", "lds_bytes"), (int(v) for v in plan)))
         self._stream.synchronize()
         torch.cuda.current_stream().wait_stream(self._stream)
         self.last_run_seconds = time.perf_counter() - t0

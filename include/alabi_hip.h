@@ -66,6 +66,33 @@ int alabi_gp_set_kernel(alabi_gp* gp, int kernel_type, double log_alpha);
 int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream);
 int alabi_gp_last_pivot(alabi_gp* gp, int* pivot /* host, 1-based like LAPACK info */);
 
+/* Batched fit + held-out mean: the k-fold cross-validation search of init_gp / _opt_gp -- alabi/gp_utils.py:511-637
+ * (_evaluate_candidate_worker: per fold deepcopy(gp), set_parameter_vector, compute(train), log_likelihood, predict(val)) mapped
+ * over the candidates by a process pool at gp_utils.py:640-700; alabi/core.py:1287-1305.  ONE call evaluates `njobs`
+ * (hyper-parameter vector, training rows, validation rows) triples that share the resident inputs X [n,d] and y [n] (device):
+ * every kernel matrix is assembled, all are factorised in one launch of the task queue (the chains of different matrices run side
+ * by side), alpha / log-likelihood / held-out mean follow in two launches, one read-back.
+ *   hyper      host [njobs][4 + d]: mean, log white noise, log amplitude, log alpha (RationalQuadratic only), log M_1..d
+ *   train_idx  device int32, the training rows of job b are train_idx[train_off[b] .. train_off[b+1]) (offsets: host int64)
+ *   val_idx    the same for the validation rows (may be empty); mu_val [val_off[njobs]] receives the held-out means
+ *   nll        host [njobs]: -log-likelihood of the training rows (+inf where K is not positive definite)
+ *   status     host [njobs]: 0, or LAPACK's 1-based pivot index where the factorisation broke down (mu_val is then NaN)
+ * Jobs are processed in chunks whose matrices fit `workspace_bytes` (0: ALABI_BATCH_BYTES or 6 GiB).  Factors are bit-identical
+ * to alabi_gp_compute on the same rows.  Synchronises with `stream`.  N <= 12288 per job. */
+typedef struct alabi_gp_batch alabi_gp_batch;
+int alabi_gp_batch_create(int d, int kernel_type, long long workspace_bytes, alabi_gp_batch** out);
+int alabi_gp_batch_destroy(alabi_gp_batch* batch);
+int alabi_gp_batch_fit_predict(alabi_gp_batch* batch, const double* X, const double* y, int n, int njobs,
+                               const double* hyper /* host */, const int* train_idx, const long long* train_off /* host */,
+                               const int* val_idx, const long long* val_off /* host */, double* mu_val,
+                               double* nll /* host */, int* status /* host */, void* stream);
+/* Factor [N,N] (zeros above the diagonal) / alpha [N] of a job of the LAST chunk processed (tests: bit-identity with the
+ * single-matrix path); ALABI_BAD_ARGUMENT for a job of an earlier chunk. */
+int alabi_gp_batch_get_factor(alabi_gp_batch* batch, int job, double* L_out, void* stream);
+int alabi_gp_batch_get_alpha(alabi_gp_batch* batch, int job, double* alpha_out, void* stream);
+/* Chunks whose queue launch ran into a bounded wait and were redone on the launch-per-step path (expected: 0). */
+int alabi_gp_batch_timeouts(alabi_gp_batch* batch, int* count /* host */);
+
 /* Extend the factorisation by ONE training point x_new[d] (device) with the hyper-parameters unchanged: the refit after every
  * active-learning iteration (alabi/core.py:1780 -> _fit_gp -> gp.compute at :1158) in O(N^2) through the cached L^-1 instead
  * of O(N^3).  Needs a free padding row (N not a multiple of 64 and N < n_cap): ALABI_BAD_ARGUMENT otherwise -- call
@@ -174,6 +201,11 @@ int alabi_ens_set_stream(alabi_ens* ens, int enabled);
  * registers (ens_stream_kernel: N <= 2048, small d), 3 = persistent group kernel (ens_group_kernel: training set
  * partitioned over groups of workgroups, kernel sums on the matrix cores; d <= 30), 0 = one launch per half step. */
 int alabi_ens_last_path(alabi_ens* ens, int* path /* host */);
+/* Blocking of the last group-kernel launch of alabi_ens_run (zeros before the first one), so a parity test can pin WHICH
+ * instantiation of ens_group_kernel it compared with the oracle: out[0] Q (16-proposal tiles per group), [1] G (members per
+ * group), [2] NG (groups per ensemble), [3] RT (point tiles per wave held in registers), [4] tpm (point tiles per member),
+ * [5] ltw (point tiles per wave staged in LDS), [6] KS (MFMA k-steps = ceil((d + 2) / 4)), [7] LDS bytes per workgroup. */
+int alabi_ens_group_plan(alabi_ens* ens, int* out /* host [8] */);
 
 /* log-probability of every walker (surrogate mean + box prior): coords [E*W,d] -> logp [E*W]. */
 int alabi_ens_lnprob(alabi_ens* ens, const double* coords, double* logp, void* stream);

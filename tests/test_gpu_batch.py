@@ -1,0 +1,149 @@
+"""GPU parity of the batched fit (alabi_gp_batch_fit_predict, alabi_amd/csrc/gp_batch.hip): the (candidate, fold) jobs of the
+k-fold cross-validation search, reference alabi/gp_utils.py:511-700 and alabi/core.py:1287-1305.
+
+* factors bit-identical to the single-matrix path (alabi_gp_compute on the same rows with the same hyper-parameters),
+  alpha / log-likelihood / held-out mean against that path and against the oracle;
+* fold scores against vectors produced by the REFERENCE's own worker (tests/golden/make_golden_cv.py);
+* a job that is not positive definite does not disturb its neighbours; the launch-per-step fallback gives the same results."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _jobs(n, d, seed, sizes, nval=37):
+    rng = np.random.RandomState(seed)
+    X, y, h = make_problem(n, d, seed, log_wn=-10.0, ell2=2.0 * d)
+    hyper, train, val = [], [], []
+    for N in sizes:
+        perm = rng.permutation(n)
+        train.append(np.sort(perm[:N])); val.append(np.sort(perm[N:N + nval]))
+        hyper.append(np.r_[h["mean"] + 0.1 * rng.randn(), -10.0 + rng.uniform(-2, 1), h["log_amp"] + 0.3 * rng.randn(), 1.0,
+                           h["log_M"] + 0.2 * rng.randn(d)])
+    return X, y, np.array(hyper), train, val
+
+
+@pytest.mark.parametrize("n,d,sizes", [
+    (1800, 6, [1600, 1601, 1536, 1100, 1700, 1664, 1280, 1599, 1600, 1345, 1024]),   # 16..27 block columns: the single path is the queue too
+    (700, 3, [64, 100, 130, 257, 600, 1, 320, 65]),                               # 1..10 block columns (single path: launch per step)
+])
+def test_batch_factors_bit_identical_and_results_match_single_path(n, d, sizes, monkeypatch):
+    import torch
+    from alabi_amd import HipGP
+    from alabi_amd.gp_batch import HipGPBatch
+    from oracle.gp_oracle import OracleGP
+    monkeypatch.setenv("ALABI_CHOL_TASKS", "1")          # the single path through the task queue at every size it supports (>= 3 block columns)
+    X, y, hyper, train, val = _jobs(n, d, 5 + d, sizes)
+    dev = torch.device("cuda")
+    Xd, yd = torch.as_tensor(X, device=dev), torch.as_tensor(y, device=dev)
+    bt = HipGPBatch(d)
+    ll, status, mu, off = bt.fit_predict(Xd, yd, hyper, train, val)
+    assert bt.timeouts == 0 and np.all(status == 0)
+    mu = mu.cpu().numpy()
+    for b, N in enumerate(sizes):
+        g = HipGP(d, hyper[b, 0], hyper[b, 1], hyper[b, 2], hyper[b, 4:])
+        g.compute(X[train[b]])
+        Ls = g.solver.get_factor().cpu().numpy()
+        Lb = bt.get_factor(b, N).cpu().numpy()
+        if N > 128:                                      # three block columns and more: both ran the same task list
+            assert np.array_equal(Ls, Lb), (b, N, np.max(np.abs(Ls - Lb)))
+        else:
+            assert np.max(np.abs(Ls - Lb)) <= 1e-13 * np.max(np.abs(Ls))
+        ll_s = g.log_likelihood(y[train[b]])
+        mu_s = g.predict(y[train[b]], X[val[b]], return_cov=False)
+        assert abs(ll[b] - ll_s) <= 1e-9 * (abs(ll_s) + 1)
+        scale = np.max(np.abs(mu_s - hyper[b, 0])) + 1e-300
+        assert np.max(np.abs(mu[off[b]:off[b + 1]] - mu_s)) <= 1e-8 * scale
+        if b < 3:                                        # the oracle on a few jobs (CPU Cholesky of 1600^2)
+            o = OracleGP(d, hyper[b, 0], hyper[b, 1], hyper[b, 2], hyper[b, 4:]).compute(X[train[b]])
+            assert abs(ll[b] - o.log_likelihood(y[train[b]])) <= 1e-8 * (abs(ll_s) + 1)
+            mu_o = o.predict(y[train[b]], X[val[b]])
+            assert np.max(np.abs(mu[off[b]:off[b + 1]] - mu_o)) <= 1e-7 * scale
+            a_o = o._compute_alpha(y[train[b]])
+            a_b = bt.get_alpha(b, N).cpu().numpy()
+            # residual form: K alpha = y - m to rounding x condition
+            K = o.get_matrix(X[train[b]])
+            r = y[train[b]] - hyper[b, 0]
+            assert np.max(np.abs(K @ a_b - r)) <= 1e-6 * np.max(np.abs(r)) and np.max(np.abs(K @ a_o - r)) <= 1e-6 * np.max(np.abs(r))
+    bt.close()
+
+
+def test_batch_not_positive_definite_job_is_isolated_and_fallback_agrees(monkeypatch):
+    import torch
+    from alabi_amd.gp_batch import HipGPBatch
+    n, d = 900, 4
+    X, y, hyper, train, val = _jobs(n, d, 17, [700, 640, 705, 512, 700])
+    X = X.copy(); X[train[2][10]] = X[train[2][3]]       # job 2 holds a duplicated row ...
+    hyper[2, 1] = -60.0                                  # ... and no nugget to speak of: not positive definite
+    dev = torch.device("cuda")
+    Xd, yd = torch.as_tensor(X, device=dev), torch.as_tensor(y, device=dev)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ALABI_BATCH_QUEUE", mode)
+        bt = HipGPBatch(d)
+        ll, status, mu, off = bt.fit_predict(Xd, yd, hyper, train, val)
+        out[mode] = (ll.copy(), status.copy(), mu.cpu().numpy().copy())
+        bt.close()
+    ll, status, mu = out["1"]
+    dup = [q for q in (2,) if status[q] != 0]
+    ok = [q for q in range(5) if q not in dup]
+    assert all(status[q] == 0 and np.isfinite(ll[q]) for q in ok)
+    if dup:                                              # (rounding may let the duplicate through: then it is simply a valid fit)
+        assert ll[2] == -np.inf and 1 <= status[2] <= 705 and np.all(np.isnan(mu[off[2]:off[3]]))
+    assert np.array_equal(out["0"][1] != 0, status != 0)
+    for q in ok:
+        assert abs(out["0"][0][q] - ll[q]) <= 1e-9 * (abs(ll[q]) + 1)
+        assert np.max(np.abs(out["0"][2][off[q]:off[q + 1]] - mu[off[q]:off[q + 1]])) <= 1e-8 * (np.max(np.abs(mu[off[q]:off[q + 1]])) + 1)
+
+
+def test_batch_chunks_and_other_kernels(monkeypatch):
+    """A workspace that holds two matrices at a time (five chunks) and the Matern / rational-quadratic families: the same numbers
+    as one chunk / as the single-matrix path."""
+    import torch
+    from alabi_amd import HipGP
+    from alabi_amd.gp_batch import HipGPBatch
+    n, d = 500, 3
+    X, y, hyper, train, val = _jobs(n, d, 23, [300, 320, 333, 384, 300, 310, 290, 256, 400])
+    dev = torch.device("cuda")
+    Xd, yd = torch.as_tensor(X, device=dev), torch.as_tensor(y, device=dev)
+    for kernel in ("ExpSquaredKernel", "Matern32Kernel", "Matern52Kernel", "RationalQuadraticKernel"):
+        big = HipGPBatch(d, kernel)
+        small = HipGPBatch(d, kernel, workspace_bytes=2 * 384 * 384 * 8)
+        r1 = big.fit_predict(Xd, yd, hyper, train, val)
+        r2 = small.fit_predict(Xd, yd, hyper, train, val)
+        np.testing.assert_array_equal(r1[0], r2[0])
+        np.testing.assert_array_equal(r1[2].cpu().numpy(), r2[2].cpu().numpy())
+        b = 4
+        g = HipGP(d, hyper[b, 0], hyper[b, 1], hyper[b, 2], hyper[b, 4:], kernel=kernel, log_alpha=hyper[b, 3])
+        g.compute(X[train[b]])
+        assert abs(r1[0][b] - g.log_likelihood(y[train[b]])) <= 1e-9 * (abs(r1[0][b]) + 1)
+        mu_s = g.predict(y[train[b]], X[val[b]], return_cov=False)
+        assert np.max(np.abs(r1[2].cpu().numpy()[r1[3][b]:r1[3][b + 1]] - mu_s)) <= 1e-8 * (np.max(np.abs(mu_s)) + 1)
+        big.close(); small.close()
+
+
+@pytest.mark.parametrize("scaler", ["none", "nlog", "minmax"])
+def test_cv_fold_scores_vs_reference_worker(scaler):
+    """cv_fold_scores (the batched per-fold body) against the fold scores the REFERENCE's _evaluate_candidate_worker returned
+    for the same folds (gp_utils.py:511-637, executed by tests/golden/make_golden_cv.py with OracleGP standing in for george):
+    mse, mae, -r2 and the probability-weighted mse, with no scaler, the reference's nlog_scaler and sklearn's MinMaxScaler."""
+    from sklearn.preprocessing import FunctionTransformer, MinMaxScaler
+    from alabi_amd import HipGP
+    from alabi_amd import gp_utils as gu
+    from alabi_amd import utility as ut
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "reference_cv_vectors.npz")))
+    theta, k = g["cv_theta"], int(g["cv_k"])
+    _y = g[f"cv_y_{scaler}"]
+    ys = {"none": ut.no_scaler, "nlog": ut.nlog_scaler, "minmax": MinMaxScaler().fit(g["cv_lnlike"].reshape(-1, 1))}[scaler]
+    gp = HipGP(theta.shape[1], 0.0, -12.0, 0.0, np.zeros(theta.shape[1]))
+    for ci, hp in enumerate(g["cv_cands"]):
+        folds = [v[v >= 0] for v in g[f"cv_val_{ci}"]]
+        for scoring in ("mse", "mae", "r2", "weighted_mse"):
+            got = gu.cv_fold_scores(gp, [hp], [folds], theta, _y, ys, scoring)[0]
+            want = g[f"cv_{scaler}_{scoring}_{ci}"]
+            assert np.all(np.isfinite(got))
+            np.testing.assert_allclose(got, want, rtol=2e-6, atol=0)

@@ -230,6 +230,69 @@ def test_C4_runs_on_the_group_kernel():
     assert np.array_equal(s._naccept.cpu().numpy(), nacc_o)
 
 
+def _config_lnp(cfg, o):
+    from oracle.gp_oracle import sqexp_kernel
+    h, b = cfg["hyper"], cfg["bounds"]
+    alpha = o._compute_alpha(cfg["y"])
+
+    def lnp(q):
+        inside = np.all((q > b[:, 0]) & (q < b[:, 1]), axis=1)
+        out = np.full(len(q), -np.inf)
+        if inside.any():
+            out[inside] = sqexp_kernel(q[inside], cfg["X"], h["log_amp"], h["log_M"]) @ alpha + h["mean"]
+        return out
+    return lnp
+
+
+def test_C5_sized_group_kernel_vs_oracle():
+    """The instantiation BASELINE's C5-sized ensemble selects (N = 10000, d = 20, 2048 walkers): wide rows (six MFMA k-steps),
+    five point tiles per wave in registers AND five staged in LDS -- the mixed register + LDS loop of the kernel sums -- compared
+    with the oracle step for step; the blocking is asserted so a planner change cannot move this test to another kernel."""
+    from alabi_amd import EnsembleSampler, HipGP
+    from alabi_amd.workloads import make_config
+    from oracle.gp_oracle import OracleGP
+    from oracle import stretch_oracle as so
+    cfg = make_config("C5")
+    h, d, b = cfg["hyper"], cfg["d"], cfg["bounds"]
+    assert (cfg["N"], d, cfg["W"]) == (10000, 20, 2048)
+    g = HipGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(cfg["X"])
+    o = OracleGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(cfg["X"])
+    nsteps = 24
+    s = EnsembleSampler(cfg["W"], d, g, cfg["y"], b, seed=4242)
+    s.run_mcmc(cfg["p0"], nsteps)
+    assert s.last_path == "group"
+    pl = s.group_plan
+    assert (pl["KS"], pl["G"], pl["Q"], pl["RT"]) == (6, 8, 2, 5) and pl["ltw"] == 5 and pl["NG"] == 32, pl
+    chain_o, lp_o, nacc_o, _, _ = so.run_ensemble(cfg["p0"], nsteps, _config_lnp(cfg, o), seed=4242)
+    assert np.max(np.abs(s.get_chain() - chain_o)) <= 1e-7
+    assert np.max(np.abs(s.get_log_prob() - lp_o) / (np.abs(lp_o) + 1)) <= 1e-8
+    assert np.array_equal(s._naccept.cpu().numpy(), nacc_o)
+    assert 0.02 < s.acceptance_fraction.mean() < 0.98
+
+
+@pytest.mark.parametrize("N,d,W,want", [
+    (8000, 10, 512, dict(KS=3, G=8, Q=1, RT=5, ltw=3)),     # narrow rows, 8 point tiles per wave: 5 in registers + 3 in LDS
+    (10000, 14, 256, dict(KS=4, G=8, Q=1, RT=5, ltw=5)),    # widest narrow row (16 words), 10 tiles per wave
+])
+def test_group_kernel_register_plus_lds_tiles_narrow_rows(N, d, W, want):
+    """Narrow rows with more point tiles per wave than the five the registers hold (N > 5120): both parts of the kernel-sum
+    loop run; chain against the oracle, blocking asserted."""
+    from alabi_amd import EnsembleSampler
+    from oracle import stretch_oracle as so
+    g, o, y = _pair(N, d, 300 + d, ell2=3.0 * d)
+    bounds = np.array([[-3.0, 3.0]] * d)
+    p0 = np.random.RandomState(15).uniform(-2, 2, (W, d))
+    s = EnsembleSampler(W, d, g, y, bounds, seed=606)
+    s.run_mcmc(p0, 30)
+    assert s.last_path == "group"
+    pl = s.group_plan
+    assert {k: pl[k] for k in want} == want, pl
+    chain_o, lp_o, nacc_o, _, _ = so.run_ensemble(p0, 30, _oracle_lnp(o, y, bounds), seed=606)
+    assert np.max(np.abs(s.get_chain() - chain_o)) <= 1e-7
+    assert np.max(np.abs(s.get_log_prob() - lp_o) / (np.abs(lp_o) + 1)) <= 1e-8
+    assert np.array_equal(s._naccept.cpu().numpy(), nacc_o)
+
+
 def test_C4_group_kernel_posterior_ks_vs_launch_per_half_step_path(monkeypatch):
     """Statistical agreement at C4 (N = 5000, 1024 walkers): two-sample KS distance per marginal between a long group-kernel
     chain and an INDEPENDENT (other seed) chain of the launch-per-half-step kernels, which equal the oracle step for step:

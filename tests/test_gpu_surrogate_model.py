@@ -247,24 +247,25 @@ def test_scan_polish_with_gpu_gradient(tmp_path):
         assert np.max(np.abs(gr - fd)) <= 1e-5 * (np.max(np.abs(fd)) + 1e-3 * abs(u))
 
 
-def test_cv_and_ml_searches_do_not_depend_on_the_thread_count(tmp_path, monkeypatch):
-    """The k-fold CV search (jobs over k streams / threads, one alabi_gp_fit_predict call per fold) and the ML restarts (one
-    thread per start) return the same hyper-parameters as their sequential forms (ALABI_CV_THREADS=1 / ALABI_ML_THREADS=1)."""
+def test_cv_and_ml_searches_do_not_depend_on_how_the_fits_are_scheduled(tmp_path, monkeypatch):
+    """The k-fold CV search returns the same hyper-parameters whether all (candidate, fold) matrices of a stage are factorised in
+    one launch of the batched task queue or one after the other on the launch-per-step path (ALABI_BATCH_QUEUE=0); the ML
+    restarts (one thread per start) return the same hyper-parameters as their sequential form (ALABI_ML_THREADS=1)."""
     from sklearn.preprocessing import StandardScaler
     from alabi_amd import SurrogateModel
     from alabi_amd.benchmarks import gaussian_shells_nd
     g = gaussian_shells_nd(3)
     out = {}
-    for method, var in (("cv", "ALABI_CV_THREADS"), ("ml", "ALABI_ML_THREADS")):
-        for nthr in ("1", "4"):
-            monkeypatch.setenv(var, nthr)
+    for method, var, settings in (("cv", "ALABI_BATCH_QUEUE", ("1", "0")), ("ml", "ALABI_ML_THREADS", ("1", "4"))):
+        for val in settings:
+            monkeypatch.setenv(var, val)
             sm = SurrogateModel(lnlike_fn=g["fn"], bounds=g["bounds"], savedir=str(tmp_path), verbose=False, random_state=7, cache=False)
             sm.init_samples(ntrain=150)
             sm.init_gp(hyperopt_method=method, y_scaler=StandardScaler(), cv_n_candidates=12, gp_nopt=3,
                        optimizer_kwargs={"maxiter": 8})
-            out[(method, nthr)] = np.array(sm.gp.get_parameter_vector())
+            out[(method, val)] = np.array(sm.gp.get_parameter_vector())
         monkeypatch.delenv(var, raising=False)
-        np.testing.assert_array_equal(out[(method, "1")], out[(method, "4")])
+        np.testing.assert_array_equal(out[(method, settings[0])], out[(method, settings[1])])
 
 
 def test_fit_predict_equals_separate_calls():

@@ -36,3 +36,53 @@ def test_utility_value_and_grad_matches_finite_differences():
                 dn = ut.utility_value_and_grad(algo, mu - h * dmu[k], var - h * dvar[k], dmu, dvar, y_best=-2.0)[0]
                 assert abs((up - dn) / (2 * h) - g[k]) <= 1e-5 * (abs(g[k]) + 1.0)
     assert ut.utility_value_and_grad("bape", 0.0, -1e-9, np.zeros(d), np.zeros(d))[0] == np.inf
+
+
+def _cv_golden():
+    import os
+    from conftest import ROOT
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "reference_cv_vectors.npz")))
+
+
+def test_kfold_splits_are_sklearns_shuffled_kfold():
+    """gp_utils.kfold_splits on RandomState(seed) = the validation sets sklearn's KFold(shuffle=True, random_state=None) drew
+    inside the reference's worker under np.random.seed(seed) (gp_utils.py:538; folds recorded by tests/golden/make_golden_cv.py)."""
+    from alabi_amd import gp_utils
+    g = _cv_golden()
+    n, k = len(g["cv_theta"]), int(g["cv_k"])
+    for ci, seed in enumerate(g["cv_seeds"]):
+        got = gp_utils.kfold_splits(n, k, np.random.RandomState(int(seed)))
+        want = [v[v >= 0] for v in g[f"cv_val_{ci}"]]
+        assert len(got) == k
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(np.sort(a), np.sort(b))
+
+
+def test_fold_scoring_rules_vs_reference_worker():
+    """gp_utils._score + _inverse_map on OracleGP predictions = the fold scores the reference's _evaluate_candidate_worker
+    returned (gp_utils.py:603-619: mse, mae, -r2, weighted mse; y un-scaled through no_scaler, nlog_scaler and a MinMaxScaler),
+    and weighted_mse_by_probability for every weighting method (gp_utils.py:449-508)."""
+    from sklearn.preprocessing import MinMaxScaler
+    from alabi_amd import gp_utils
+    from alabi_amd import utility as ut
+    from oracle.gp_oracle import OracleGP
+    g = _cv_golden()
+    theta = g["cv_theta"]
+    d = theta.shape[1]
+    for scaler in ("none", "nlog", "minmax"):
+        _y = g[f"cv_y_{scaler}"]
+        ys = {"none": ut.no_scaler, "nlog": ut.nlog_scaler, "minmax": MinMaxScaler().fit(g["cv_lnlike"].reshape(-1, 1))}[scaler]
+        inv = gp_utils._inverse_map(ys)
+        for ci, hp in enumerate(g["cv_cands"]):
+            folds = [v[v >= 0] for v in g[f"cv_val_{ci}"]]
+            for kf, val in enumerate(folds):
+                train = np.setdiff1d(np.arange(len(theta)), val)
+                o = OracleGP(d, hp[0], hp[1], hp[2], hp[3:]).compute(theta[train])
+                pred = o.predict(_y[train], theta[val])
+                for scoring in ("mse", "mae", "r2", "weighted_mse"):
+                    got = gp_utils._score(inv(_y[val]), inv(pred), scoring)
+                    np.testing.assert_allclose(got, g[f"cv_{scaler}_{scoring}_{ci}"][kf], rtol=1e-9)
+    for method in ("exponential", "linear", "softmax", "rank"):
+        for temp in (1.0, 2.5):
+            got = gp_utils.weighted_mse_by_probability(g["wmse_true"], g["wmse_pred"], weight_method=method, temperature=temp)
+            np.testing.assert_allclose(got, g[f"wmse_{method}_{temp}"], rtol=1e-13)
