@@ -54,6 +54,7 @@ SIGNATURES = {
     "alabi_gp_set_mean": (_i, [_vp, _d]),
     "alabi_gp_get_alpha": (_i, [_vp, _vp, _vp]),
     "alabi_gp_get_factor": (_i, [_vp, _vp, _vp]),
+    "alabi_gp_get_inverse": (_i, [_vp, _vp, _vp]),
     "alabi_gp_n": (_i, [_vp, _pi]),
     "alabi_kernel_matrix": (_i, [_vp, _i, _vp, _i, _i, _i, _d, _d, _pd, _vp, _vp]),
     "alabi_utility_scan": (_i, [_vp, _i, _vp, _ll, _pd, _d, _vp, _vp, _vp, _pd, _pll, _vp]),

@@ -362,6 +362,12 @@ int alabi_gp_get_factor(alabi_gp* gp, double* L_out, void* stream) {
     return ALABI_OK;
 }
 
+int alabi_gp_get_inverse(alabi_gp* gp, double* Kinv_out, void* stream) {
+    if (!gp || !Kinv_out) return ALABI_BAD_ARGUMENT;
+    if (!gp->computed) return ALABI_NOT_COMPUTED;
+    return launch_get_inverse(gp, Kinv_out, as_stream(stream));
+}
+
 int alabi_kernel_matrix(const double* X1, int n1, const double* X2, int n2, int d, int kernel_type, double log_alpha,
                         double log_amp, const double* log_M, double* K_out, void* stream) {
     if (!X1 || !X2 || !K_out || !log_M || n1 <= 0 || n2 <= 0 || d <= 0 || d > ALABI_MAX_DIM || kernel_type < 0 ||

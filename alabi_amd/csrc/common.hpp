@@ -178,7 +178,7 @@ struct CholTask;
 struct CholMat;
 struct CholBatchQueue {
     std::vector<int> nbs;                       // key of the cached task list: block columns per matrix, lists, window
-    int nlists = 0, window = 0, B = 0;
+    int nlists = 0, window = 0, B = 0, shape_sig = 0;
     CholTask* tasks = nullptr; size_t tasks_cap = 0; int ntasks = 0;
     int* list_off = nullptr;                    // device [nlists + 1]
     CholMat* mats = nullptr; size_t mats_cap = 0;
@@ -209,6 +209,7 @@ int ensure_winv(alabi_gp* gp, hipStream_t s);        // the cached L^-1 of the c
 int launch_factor_inverse_into(alabi_gp* gp, double* dst, hipStream_t s);
 int launch_predict_var_small(alabi_gp* gp, const double* Xs, int M, double* mu, double* var, hipStream_t s);
 int launch_grad_log_likelihood(alabi_gp* gp, double* grad_dev, hipStream_t s);
+int launch_get_inverse(alabi_gp* gp, double* Kinv_out, hipStream_t s);   // gp_grad.hip: K^-1 = W^T W, [N,N] row-major
 int launch_predict_var(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var,
                        hipStream_t s);
 // utility.hip

@@ -1446,6 +1446,48 @@ static void chol_build_tasks(int nb, int gk, int near, bool two, std::vector<Cho
     }
 }
 
+// The list for a matrix that shares the queue with many others (chol_batch_build).  There the chip is kept busy by the OTHER
+// matrices, so nothing has to be fed to a matrix's own chain early and no tile takes a block column on its own: every tile receives
+// full groups of gk block columns while the chain is far, and ONE catch-up task brings it up to date at the last moment --
+//   off-diagonal (i, j): at step j - 1 (then TRSM(i, j) / CHAIN(j) can solve it), diagonal (j, j): at step j - 2 (CHAIN(j) applies
+//   column j - 1 itself); the catch-up covers [gk floor(c / gk), c] for catch-up step c, the groups before it are complete.
+// With gk >= nb this is the left-looking factorisation: every tile is read and written once.  Against the list above (near = 4):
+// 276 single-column tasks fewer per matrix of 25 block columns, each of which paid a task's fixed cost (queue draw, dependency
+// poll, first fetch, C round trip) for 64 matrix-core instructions per wave.  Every tile still receives its block columns in
+// ascending order inside register accumulators: the same bits.
+static void chol_build_tasks_batch(int nb, int gk, bool two, bool four, std::vector<CholTask>& t) {
+    t.clear();
+    t.push_back({0, 0, 0, 0});
+    auto grouped = [&](int j, int i0, int cnt, int k0) {                 // tiles (i, j), i = i0 .. nb - 1, block columns k0 .. k0 + cnt - 1
+        for (int i = i0; i < nb; ++i) {
+            if (two && cnt >= 2 && i + 1 < nb) { t.push_back({4 | (cnt << 8), i, j, k0}); ++i; }
+            else t.push_back({2 | (cnt << 8), i, j, k0});
+        }
+    };
+    for (int k = 0; k + 1 < nb; ++k) {
+        t.push_back({0, k + 1, k + 1, k + 1});
+        for (int i = k + 2; i < nb; ++i) t.push_back({1, i, k, k});
+        const int c0 = k / gk * gk, cc = k + 1 - c0;                      // catch-ups of this step: block columns [c0, k]
+        grouped(k + 1, k + 2, cc, c0);                                    // column k + 1 below its diagonal tile
+        if (k + 2 < nb) t.push_back({2 | (cc << 8), k + 2, k + 2, c0});   // diagonal tile (k + 2, k + 2)
+        if ((k + 1) % gk == 0) {                                          // a group is complete: everything whose catch-up is still ahead
+            const int k0 = k + 1 - gk;
+            grouped(k + 2, k + 3, gk, k0);                                // column k + 2 without its diagonal tile (caught up above)
+            for (int j = k + 3; j < nb; ++j) {
+                if (four && gk >= 2 && j + 1 < nb) {                      // tile columns j and j + 1: (j, j) alone, then 2 x 2 blocks
+                    t.push_back({2 | (gk << 8), j, j, k0});
+                    int i = j + 1;
+                    for (; i + 1 < nb; i += 2) t.push_back({5 | (gk << 8), i, j, k0});
+                    if (i < nb) { t.push_back({2 | (gk << 8), i, j, k0}); t.push_back({2 | (gk << 8), i, j + 1, k0}); }
+                    ++j;
+                    continue;
+                }
+                grouped(j, j, gk, k0);
+            }
+        }
+    }
+}
+
 // Block columns per far update and width of the near band, by size: measured in tools/prof_cholesky.py
 static void chol_task_shape(int nb, int* gk, int* near) {
     // measured (profiles/r03_cholesky_task_shapes.txt): N = 2000: (4,4) 0.585 ms, (8,4) 0.578, (16,3) 0.627; N = 3072: (4,2) 0.98,
@@ -1673,14 +1715,31 @@ int launch_cholesky(alabi_gp* gp, hipStream_t s) { return launch_cholesky_steps(
 //     ~ P * nlists lower triangles instead of all B;
 //   * within a slot the matrices closest to their end come first (their steps are short and chain-bound).
 // Each matrix keeps the order of its own list, so every list remains a topological order.
+// ALABI_BATCH_GK: block columns per group, ALABI_BATCH_LEFT=0: the single-matrix list instead.  Measured (tools/prof_batch_cv.py, 500
+// matrices of N = 1600 per call, everything included): the single-matrix list 46.6 ms; this one 34.3 (gk 4), 31.9 (8), 31.8 (10), 32.1 (12),
+// 35.5 (16), 36.9 (32 = left-looking) -- profiles/r04_batch_sweeps.txt
+static int chol_batch_gk() {
+    int gk = 10;
+    if (const char* e = getenv("ALABI_BATCH_GK")) { const int v = atoi(e); if (v >= 1 && v <= 255) gk = v; }
+    return gk;
+}
+static bool chol_batch_left() { const char* e = getenv("ALABI_BATCH_LEFT"); return !(e && e[0] == '0'); }
+static void chol_batch_shape(int nb, std::vector<CholTask>& t) {
+    if (chol_batch_left()) {
+        const char* e4 = getenv("ALABI_CHOL_UPDATE4");
+        chol_build_tasks_batch(nb, chol_batch_gk(), true, !(e4 && e4[0] == '0'), t);
+        return;
+    }
+    int gk, near;
+    chol_task_shape(nb, &gk, &near);
+    chol_build_tasks(nb, gk, near, chol_tasks_two(nb, gk), t);
+}
 static int chol_batch_build(const std::vector<int>& nbs, int nlists, int window, std::vector<CholTask>& out, std::vector<int>& list_off) {
     std::map<int, std::pair<std::vector<CholTask>, std::vector<int>>> per_nb;       // nb -> (tasks, first task of every step)
     for (int nb : nbs) {
         if (per_nb.count(nb)) continue;
-        int gk, near;
-        chol_task_shape(nb, &gk, &near);
         auto& e = per_nb[nb];
-        chol_build_tasks(nb, gk, near, chol_tasks_two(nb, gk), e.first);
+        chol_batch_shape(nb, e.first);
         for (size_t q = 0; q < e.first.size(); ++q)
             if ((e.first[q].type & 255) == 0) e.second.push_back((int)q);            // a CHAIN task opens a step
         e.second.push_back((int)e.first.size());
@@ -1716,6 +1775,14 @@ static int chol_batch_build(const std::vector<int>& nbs, int nlists, int window,
     return (int)out.size();
 }
 
+extern "C" int alabi_debug_chol_batch_matrix_tasks(int nb, int* out, int cap) {   // host only: ONE matrix's list inside a batch
+    std::vector<CholTask> t;
+    chol_batch_shape(nb, t);
+    if (out)
+        for (size_t q = 0; q < t.size() && (int)q < cap; ++q) { out[4 * q] = t[q].type; out[4 * q + 1] = t[q].i; out[4 * q + 2] = t[q].j; out[4 * q + 3] = t[q].k; }
+    return (int)t.size();
+}
+
 extern "C" int alabi_debug_chol_batch_tasks(int B, const int* nbs, int nlists, int window, int* out, int cap, int* list_off_out) {
     std::vector<int> v(nbs, nbs + B), lo;
     std::vector<CholTask> t;
@@ -1738,7 +1805,7 @@ void chol_batch_free(CholBatchQueue& q) {
 // builds (or reuses) the interleaved task list, uploads the matrix table, clears the control words -- everything on `s`.
 int chol_batch_prepare(CholBatchQueue& q, int B, const int* ld, double* const* A, double* const* dinv, int* const* info, hipStream_t s) {
     if (B <= 0 || B >= 32768) return ALABI_BAD_ARGUMENT;
-    int nlists = 8, window = 3;
+    int nlists = 8, window = 8;      // measured: window 2 45 ms, 3 40, 4 35.6, 5 33.2, 8 31.8, 0 (all at once) 31.4-32.4 per 500 matrices of N = 1600
     if (const char* e = getenv("ALABI_BATCH_LISTS")) { const int v = atoi(e); if (v >= 1 && v <= 8) nlists = v; }
     if (const char* e = getenv("ALABI_BATCH_WINDOW")) { const int v = atoi(e); if (v >= 0 && v <= 4096) window = v; }
     if (nlists > B) nlists = B;
@@ -1749,7 +1816,14 @@ int chol_batch_prepare(CholBatchQueue& q, int B, const int* ld, double* const* A
         nbs[b] = ld[b] / 64;
         ver_ints += (size_t)nbs[b] * nbs[b] + nbs[b];
     }
-    if (!(q.tasks && q.nbs == nbs && q.nlists == nlists && q.window == window)) {
+    int shape_sig = 0;                                                    // the switches that shape a matrix's own list (tools: env sweeps)
+    {
+        int gk, near;
+        chol_task_shape(nbs[0], &gk, &near);
+        const char* e4 = getenv("ALABI_CHOL_UPDATE4");
+        shape_sig = (chol_batch_left() ? 1 << 20 : 0) + chol_batch_gk() * 4096 + gk * 64 + near * 4 + (e4 ? (e4[0] == '1' ? 1 : 3) : 0);
+    }
+    if (!(q.tasks && q.nbs == nbs && q.nlists == nlists && q.window == window && q.shape_sig == shape_sig)) {
         std::vector<CholTask> t;
         std::vector<int> lo;
         chol_batch_build(nbs, nlists, window, t, lo);
@@ -1762,7 +1836,7 @@ int chol_batch_prepare(CholBatchQueue& q, int B, const int* ld, double* const* A
         ALABI_HIP_CHECK(hipStreamSynchronize(s));                         // a launch still reading the previous list
         ALABI_HIP_CHECK(hipMemcpy(q.tasks, t.data(), t.size() * sizeof(CholTask), hipMemcpyHostToDevice));
         ALABI_HIP_CHECK(hipMemcpy(q.list_off, lo.data(), (nlists + 1) * sizeof(int), hipMemcpyHostToDevice));
-        q.ntasks = (int)t.size(); q.nbs = nbs; q.nlists = nlists; q.window = window;
+        q.ntasks = (int)t.size(); q.nbs = nbs; q.nlists = nlists; q.window = window; q.shape_sig = shape_sig;
     }
     if ((size_t)B > q.mats_cap) {
         if (q.mats) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(q.mats); q.mats = nullptr; }

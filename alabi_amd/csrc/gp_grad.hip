@@ -34,34 +34,16 @@ __device__ inline void radial_with_derivative(double r2, KernelFn kf, double& f,
     dlog_alpha = kf.alpha * f * (u / (1.0 + u) - l);
 }
 
-// partial[block][0] = sum A (K - wn I), [1] = trace part, [2] = log_alpha part, [3 + k] = log_M_k part
-template <int D>
-__global__ void __launch_bounds__(256)
-grad_contract_kernel(const double* __restrict__ W, const double* __restrict__ Xt, const double* __restrict__ alpha,
-                     int N, int Npad, double amp, KernelFn kf, double* __restrict__ partial) {
-    __shared__ double xa_s[D][64], xb_s[D][64];
-    __shared__ double al_a[64], al_b[64];
-    __shared__ double scratch[16];
-    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    // block index -> (ta, tb), tb <= ta
-    const int p = blockIdx.x;
-    int ta = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
-    while ((ta + 1) * (ta + 2) / 2 <= p) ++ta;
-    while (ta * (ta + 1) / 2 > p) --ta;
-    const int tb = p - ta * (ta + 1) / 2;
-    for (int e = tid; e < D * 64; e += 256) {
-        xa_s[e >> 6][e & 63] = Xt[(size_t)(e >> 6) * Npad + ta * 64 + (e & 63)];
-        xb_s[e >> 6][e & 63] = Xt[(size_t)(e >> 6) * Npad + tb * 64 + (e & 63)];
-    }
-    if (tid < 64) { al_a[tid] = alpha[ta * 64 + tid]; al_b[tid] = alpha[tb * 64 + tid]; }
-    // K^-1 block = sum over 64-row slabs n0 >= 64 ta of Wa_slab^T Wb_slab: both slabs (64 x 64, row n, column a / b) are
-    // staged in LDS through registers one slab ahead (16-byte coalesced loads), wave w owns output rows 16w..16w+15, four
-    // 16-column tiles.  MFMA operand layout (gfx950, 16x16x4 f64): A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k,
-    // C[(lane >> 4) + 4 i][lane & 15] in element i; with the slabs stored [k][i] both operands are conflict-free row reads.
+// The 64 x 64 block (ta, tb), tb <= ta, of K^-1 = W^T W from the tile-major W = L^-1: the sum over 64-row slabs n0 >= 64 ta of
+// Wa_slab^T Wb_slab.  Both slabs (64 x 64, row n, column a / b) are staged in LDS through registers one slab ahead (16-byte
+// coalesced loads), wave w owns output rows 16w..16w+15, four 16-column tiles.  MFMA operand layout (gfx950, 16x16x4 f64):
+// A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k, C[(lane >> 4) + 4 i][lane & 15] in element i; with the slabs stored
+// [k][i] both operands are conflict-free row reads.  256 threads; acc[c][i] = block[16 w + (lane >> 4) + 4 i][16 c + (lane & 15)].
+__device__ inline void kinv_block(const double* __restrict__ W, int Npad, int ta, int tb, v4f64 (&acc)[4]) {
     __shared__ double Sa[64][66], Sb[64][66];
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const f64x2* Wa2 = reinterpret_cast<const f64x2*>(W + (size_t)ta * Npad * 64);
     const f64x2* Wb2 = reinterpret_cast<const f64x2*>(W + (size_t)tb * Npad * 64);
-    v4f64 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = v4f64{0.0, 0.0, 0.0, 0.0};
     f64x2 pa[8], pb[8];
@@ -92,6 +74,53 @@ grad_contract_kernel(const double* __restrict__ W, const double* __restrict__ Xt
                 acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Sb[4 * ks + (l >> 4)][16 * c + (l & 15)], acc[c], 0, 0, 0);
         }
     }
+}
+
+// solver.get_inverse() (reference: alabi/utility.py:610, the finite-difference acquisition gradient): K^-1 [N,N] row-major, both
+// triangles, one workgroup per block (ta >= tb) of the lower triangle writing the block and its mirror image.
+__global__ void __launch_bounds__(256)
+kinv_write_kernel(const double* __restrict__ W, int N, int Npad, double* __restrict__ out) {
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int p = blockIdx.x;
+    int ta = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+    while ((ta + 1) * (ta + 2) / 2 <= p) ++ta;
+    while (ta * (ta + 1) / 2 > p) --ta;
+    const int tb = p - ta * (ta + 1) / 2;
+    v4f64 acc[4];
+    kinv_block(W, Npad, ta, tb, acc);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ga = ta * 64 + 16 * w + (l >> 4) + 4 * i, gb = tb * 64 + 16 * c + (l & 15);
+            if (ga >= N || gb >= N) continue;
+            out[(size_t)ga * N + gb] = acc[c][i];
+            if (ta != tb) out[(size_t)gb * N + ga] = acc[c][i];
+        }
+}
+
+// partial[block][0] = sum A (K - wn I), [1] = trace part, [2] = log_alpha part, [3 + k] = log_M_k part
+template <int D>
+__global__ void __launch_bounds__(256)
+grad_contract_kernel(const double* __restrict__ W, const double* __restrict__ Xt, const double* __restrict__ alpha,
+                     int N, int Npad, double amp, KernelFn kf, double* __restrict__ partial) {
+    __shared__ double xa_s[D][64], xb_s[D][64];
+    __shared__ double al_a[64], al_b[64];
+    __shared__ double scratch[16];
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    // block index -> (ta, tb), tb <= ta
+    const int p = blockIdx.x;
+    int ta = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+    while ((ta + 1) * (ta + 2) / 2 <= p) ++ta;
+    while (ta * (ta + 1) / 2 > p) --ta;
+    const int tb = p - ta * (ta + 1) / 2;
+    for (int e = tid; e < D * 64; e += 256) {
+        xa_s[e >> 6][e & 63] = Xt[(size_t)(e >> 6) * Npad + ta * 64 + (e & 63)];
+        xb_s[e >> 6][e & 63] = Xt[(size_t)(e >> 6) * Npad + tb * 64 + (e & 63)];
+    }
+    if (tid < 64) { al_a[tid] = alpha[ta * 64 + tid]; al_b[tid] = alpha[tb * 64 + tid]; }
+    v4f64 acc[4];
+    kinv_block(W, Npad, ta, tb, acc);
     __syncthreads();
     double s_amp = 0.0, s_tr = 0.0, s_al = 0.0, s_m[D];
 #pragma unroll
@@ -148,15 +177,30 @@ grad_final_kernel(const double* __restrict__ partial, int nblocks, int stride, c
     }
 }
 
-int launch_grad_log_likelihood(alabi_gp* gp, double* grad_dev, hipStream_t s) {
-    // L^-1: the cache the variance path keeps per factor; into the variance workspace when there is no room for the cache
-    const double* Wsrc = nullptr;
+// W = L^-1 of the current factor: the cache the variance path keeps per factor, or the variance workspace when there is no room
+static int factor_inverse_source(alabi_gp* gp, hipStream_t s, const double** Wsrc) {
     int st = ensure_winv(gp, s);
-    if (st == ALABI_OK) Wsrc = gp->winv;
-    else if (st == ALABI_NOT_COMPUTED) {
-        if ((st = launch_factor_inverse(gp, s)) != ALABI_OK) return st;
-        Wsrc = gp->ws;
-    } else return st;
+    if (st == ALABI_OK) { *Wsrc = gp->winv; return ALABI_OK; }
+    if (st != ALABI_NOT_COMPUTED) return st;
+    if ((st = launch_factor_inverse(gp, s)) != ALABI_OK) return st;
+    *Wsrc = gp->ws;
+    return ALABI_OK;
+}
+
+int launch_get_inverse(alabi_gp* gp, double* out, hipStream_t s) {
+    const double* Wsrc = nullptr;
+    int st = factor_inverse_source(gp, s, &Wsrc);
+    if (st != ALABI_OK) return st;
+    const int nb = gp->Npad / 64;
+    hipLaunchKernelGGL(kinv_write_kernel, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, Wsrc, gp->N, gp->Npad, out);
+    ALABI_LAUNCH_CHECK();
+    return ALABI_OK;
+}
+
+int launch_grad_log_likelihood(alabi_gp* gp, double* grad_dev, hipStream_t s) {
+    const double* Wsrc = nullptr;
+    int st = factor_inverse_source(gp, s, &Wsrc);
+    if (st != ALABI_OK) return st;
     const int nb = gp->Npad / 64, nblocks = nb * (nb + 1) / 2;
     const int db = dim_bucket(gp->d);
     const size_t need = (size_t)nblocks * (db + 3) * sizeof(double);

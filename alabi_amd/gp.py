@@ -97,12 +97,17 @@ class _SolverView:
         _lib.check(_lib.lib().alabi_gp_get_factor(gp._handle, _lib.ptr(out), _lib.current_stream()), "alabi_gp_get_factor")
         return out
 
+    def get_inverse_device(self):
+        """K^-1 [N,N] (device tensor) = W^T W on the matrix cores from the library's cached W = L^-1 (alabi_gp_get_inverse)."""
+        gp = self._gp
+        gp._require_computed()
+        out = torch.empty((gp._n, gp._n), dtype=torch.float64, device=_dev())
+        _lib.check(_lib.lib().alabi_gp_get_inverse(gp._handle, _lib.ptr(out), _lib.current_stream()), "alabi_gp_get_inverse")
+        return out
+
     def get_inverse(self):
-        # K^-1 = L^-T L^-1 from the native factor (interim: the two triangular solves against the
-        # identity use torch; only the finite-difference gradient helpers of the reference need it)
-        L = self.get_factor()
-        eye = torch.eye(L.shape[0], dtype=torch.float64, device=L.device)
-        return torch.cholesky_solve(eye, L).cpu().numpy()
+        """george's solver.get_inverse() (reference: alabi/utility.py:610)."""
+        return self.get_inverse_device().cpu().numpy()
 
 
 class HipGP:

@@ -52,26 +52,39 @@ class HipGPBatch:
         ``val_sets``: B integer arrays of rows of ``theta_dev`` [n, d] / ``y_dev`` [n] (device, float64).
         Returns (log-likelihood [B] (-inf where K is not positive definite), status [B], mu, val_off) with ``mu`` ONE device
         tensor holding every job's held-out means, job b at mu[val_off[b]:val_off[b + 1]]."""
-        hyper = np.ascontiguousarray(np.asarray(hyper, dtype=np.float64))
         B = len(train_sets)
-        if hyper.shape != (B, 4 + self.ndim) or len(val_sets) != B:
-            raise ValueError("hyper must be [len(train_sets), 4 + ndim] and val_sets as long as train_sets")
+        if len(val_sets) != B:
+            raise ValueError("val_sets must be as long as train_sets")
+        n = int(theta_dev.shape[0])
+        tr_off = np.zeros(B + 1, dtype=np.int64); np.cumsum([len(t) for t in train_sets], out=tr_off[1:])
+        va_off = np.zeros(B + 1, dtype=np.int64); np.cumsum([len(v) for v in val_sets], out=va_off[1:])
+        tr_all = np.concatenate([np.asarray(t).ravel() for t in train_sets]).astype(np.int32, copy=False) if B else np.zeros(0, np.int32)
+        va_all = np.concatenate([np.asarray(v).ravel() for v in val_sets]).astype(np.int32, copy=False) if B else np.zeros(0, np.int32)
+        for a in (tr_all, va_all):
+            if a.size and (a.min() < 0 or a.max() >= n):
+                raise ValueError("row index out of range")
+        dev = theta_dev.device
+        return self.fit_predict_indexed(theta_dev, y_dev, hyper, torch.as_tensor(tr_all, device=dev), tr_off,
+                                        torch.as_tensor(va_all, device=dev) if va_all.size else None, va_off)
+
+    def fit_predict_indexed(self, theta_dev, y_dev, hyper, tr_dev, tr_off, va_dev, va_off):
+        """The same with the row lists already on the device: ``tr_dev`` / ``va_dev`` int32 tensors holding every job's rows one
+        after the other (rows must lie in [0, n): NOT checked here), ``tr_off`` / ``va_off`` host int64 offsets [B + 1]."""
+        hyper = np.ascontiguousarray(np.asarray(hyper, dtype=np.float64))
+        tr_off = np.ascontiguousarray(tr_off, dtype=np.int64)
+        va_off = np.ascontiguousarray(va_off, dtype=np.int64)
+        B = len(tr_off) - 1
+        if hyper.shape != (B, 4 + self.ndim) or len(va_off) != B + 1:
+            raise ValueError("hyper must be [jobs, 4 + ndim] and the offset arrays [jobs + 1]")
         n = int(theta_dev.shape[0])
         if theta_dev.dtype != torch.float64 or y_dev.dtype != torch.float64 or tuple(theta_dev.shape) != (n, self.ndim) \
                 or tuple(y_dev.shape) != (n,) or not theta_dev.is_contiguous() or not y_dev.is_contiguous():
             raise ValueError("theta_dev [n, ndim] / y_dev [n] must be contiguous float64 device tensors")
-        tr = [np.asarray(t, dtype=np.int32).ravel() for t in train_sets]
-        va = [np.asarray(v, dtype=np.int32).ravel() for v in val_sets]
-        for a in tr + va:
-            if a.size and (a.min() < 0 or a.max() >= n):
-                raise ValueError("row index out of range")
-        tr_off = np.zeros(B + 1, dtype=np.int64); np.cumsum([len(t) for t in tr], out=tr_off[1:])
-        va_off = np.zeros(B + 1, dtype=np.int64); np.cumsum([len(v) for v in va], out=va_off[1:])
+        if tr_dev.dtype != torch.int32 or tr_dev.numel() != tr_off[-1] or (va_off[-1] > 0 and (va_dev is None or va_dev.dtype != torch.int32
+                                                                                              or va_dev.numel() != va_off[-1])):
+            raise ValueError("row lists must be int32 device tensors matching the offsets")
         dev = theta_dev.device
-        tr_dev = torch.as_tensor(np.concatenate(tr) if B else np.zeros(0, np.int32), device=dev)
-        va_all = np.concatenate(va) if B else np.zeros(0, np.int32)
-        va_dev = torch.as_tensor(va_all, device=dev) if va_all.size else None
-        mu = torch.empty(int(va_off[-1]), dtype=torch.float64, device=dev) if va_all.size else None
+        mu = torch.empty(int(va_off[-1]), dtype=torch.float64, device=dev) if va_off[-1] > 0 else None
         nll = np.empty(B, dtype=np.float64)
         status = np.empty(B, dtype=np.int32)
         st = _lib.lib().alabi_gp_batch_fit_predict(

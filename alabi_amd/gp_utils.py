@@ -129,6 +129,83 @@ def kfold_splits(n, k_folds, rng):
     return np.array_split(rng.permutation(n), k_folds)
 
 
+def _segment_scores(y_val, y_pred, off, scoring, weighted_mse_method="exponential", weighted_mse_factor=1.0):
+    """_score for every segment [off[b], off[b + 1]) of the concatenated un-scaled (y_val, y_pred) at once (np.add.reduceat);
+    None where the rule has no vectorised form (the caller then scores segment by segment)."""
+    lens = np.diff(off).astype(np.float64)
+    starts = np.asarray(off[:-1], dtype=np.int64)
+    if len(starts) == 0 or np.any(lens <= 0):
+        return None
+    seg = lambda v: np.add.reduceat(v, starts)  # noqa: E731
+    e2 = (y_val - y_pred) ** 2
+    with np.errstate(all="ignore"):
+        if scoring == "mse":
+            return seg(e2) / lens
+        if scoring == "mae":
+            return seg(np.abs(y_val - y_pred)) / lens
+        if scoring == "r2":
+            mean = np.repeat(seg(y_val) / lens, np.diff(off))
+            return -(1.0 - seg(e2) / seg((y_val - mean) ** 2))
+        if scoring == "weighted_mse" and weighted_mse_method in ("exponential", "softmax", "linear"):
+            if weighted_mse_method == "linear":
+                w = y_val - np.repeat(np.minimum.reduceat(y_val, starts), np.diff(off)) + 1e-6
+            else:
+                w = np.exp(y_val / weighted_mse_factor)
+            return seg(w * e2) / seg(w)                   # = np.average(e2, weights=w / mean(w))
+    return None
+
+
+def _cv_scores(gp, hyper_rows, fold_of, k_folds, _y, dev, inv, scoring, weighted_mse_method, weighted_mse_factor, batch):
+    """Scores [C][k] of C hyper-parameter rows (HipGP.full_hyper) whose folds are given as fold_of [C, n] (fold number of every
+    row, -1 = in no fold): the row lists of all C k jobs are built on the device (ascending rows on both sides, as sklearn's
+    KFold.split yields them), ONE batched library call, one read-back of the held-out means, vectorised scoring."""
+    import torch
+    C = len(hyper_rows)
+    out = np.full((C, k_folds), np.inf)
+    if C == 0:
+        return out
+    fo = torch.as_tensor(np.ascontiguousarray(fold_of, dtype=np.int8), device=dev[0].device)           # [C, n]
+    kk = torch.arange(k_folds, dtype=torch.int8, device=fo.device)[None, :, None]
+    is_val = fo[:, None, :] == kk                                                                       # [C, k, n]
+    is_train = (~is_val) & (fo >= 0)[:, None, :]
+    va_dev = is_val.nonzero()[:, 2].to(torch.int32)                                                     # sorted by (c, k, row)
+    tr_dev = is_train.nonzero()[:, 2].to(torch.int32)
+    counts = np.stack([(fold_of == q).sum(axis=1) for q in range(k_folds)], axis=1).astype(np.int64)   # [C, k] rows per fold
+    used = (fold_of >= 0).sum(axis=1).astype(np.int64)
+    va_off = np.zeros(C * k_folds + 1, dtype=np.int64); np.cumsum(counts.ravel(), out=va_off[1:])
+    tr_off = np.zeros(C * k_folds + 1, dtype=np.int64); np.cumsum((used[:, None] - counts).ravel(), out=tr_off[1:])
+    hyper = np.repeat(np.asarray(hyper_rows, dtype=np.float64), k_folds, axis=0)
+    ll, status, mu, off = batch.fit_predict_indexed(dev[0], dev[1], hyper, tr_dev, tr_off, va_dev, va_off)
+    if mu is None:
+        return out
+    mu_host = mu.cpu().numpy()
+    val_rows = va_dev.cpu().numpy()
+    good = (status == 0) & np.isfinite(ll) & (np.diff(off) > 0)
+    fin = np.isfinite(mu_host)
+    if not np.all(fin):
+        good &= np.add.reduceat((~fin).astype(np.int64), off[:-1].clip(max=len(mu_host) - 1)) == 0
+    sc = None
+    try:
+        y_val, y_pred = inv(_y[val_rows]), inv(np.where(fin, mu_host, 0.0))
+        sc = _segment_scores(y_val, y_pred, off, scoring, weighted_mse_method, weighted_mse_factor)
+    except Exception:  # noqa: BLE001 - e.g. a scaler that rejects the whole array: score fold by fold below
+        sc = None
+    flat = out.reshape(-1)
+    if sc is not None:
+        ok = good & np.isfinite(sc)
+        flat[ok] = sc[ok]
+        return out
+    for b in np.flatnonzero(good):
+        try:
+            v = _score(inv(_y[val_rows[off[b]:off[b + 1]]]), inv(mu_host[off[b]:off[b + 1]]), scoring, weighted_mse_method,
+                       weighted_mse_factor)
+        except Exception:  # noqa: BLE001 - the reference marks a fold that raises as failed
+            continue
+        if np.isfinite(v):
+            flat[b] = v
+    return out
+
+
 def cv_fold_scores(gp, candidates, fold_sets, _theta, _y, y_scaler, scoring="mse", weighted_mse_method="exponential",
                    weighted_mse_factor=1.0, batch=None, dev=None, inv=None):
     """Fold scores of several hyper-parameter vectors in ONE batched library call (gp_utils.py:511-637 per candidate):
@@ -138,6 +215,12 @@ def cv_fold_scores(gp, candidates, fold_sets, _theta, _y, y_scaler, scoring="mse
     non-finite likelihood or predictions, as the reference's per-fold try/except)."""
     from .gp import _to_dev
     from .gp_batch import HipGPBatch
+    _y = np.asarray(_y, dtype=np.float64).ravel()
+    if not len(candidates):
+        return []
+    k_folds = len(fold_sets[0])
+    if any(len(f) != k_folds for f in fold_sets):
+        raise ValueError("every candidate needs the same number of folds")
     own = batch is None
     if own:
         batch = HipGPBatch(gp.ndim, gp.kernel_name)
@@ -145,32 +228,12 @@ def cv_fold_scores(gp, candidates, fold_sets, _theta, _y, y_scaler, scoring="mse
         inv = _inverse_map(y_scaler) if inv is None else inv
         if dev is None:
             dev = (_to_dev(np.ascontiguousarray(_theta, dtype=np.float64), 2), _to_dev(np.ascontiguousarray(_y, dtype=np.float64)))
-        hyper, train, val, owner = [], [], [], []
-        for c, (hp, folds) in enumerate(zip(candidates, fold_sets)):
-            row = gp.full_hyper(hp)
-            for k in range(len(folds)):
-                v = np.sort(np.asarray(folds[k]))
-                t = np.sort(np.concatenate([folds[q] for q in range(len(folds)) if q != k]))
-                hyper.append(row); train.append(t); val.append(v); owner.append(c)
-        out = [[np.inf] * len(f) for f in fold_sets]
-        if not hyper:
-            return out
-        ll, status, mu, off = batch.fit_predict(dev[0], dev[1], np.array(hyper), train, val)
-        mu_host = mu.cpu().numpy() if mu is not None else np.zeros(0)
-        pos = [0] * len(fold_sets)
-        for b, c in enumerate(owner):
-            k = pos[c]; pos[c] += 1
-            if status[b] != 0 or not np.isfinite(ll[b]):
-                continue
-            pred = mu_host[off[b]:off[b + 1]]
-            if pred.size == 0 or not np.all(np.isfinite(pred)):
-                continue
-            try:
-                sc = _score(inv(_y[val[b]]), inv(pred), scoring, weighted_mse_method, weighted_mse_factor)
-            except Exception:  # noqa: BLE001
-                continue
-            out[c][k] = sc if np.isfinite(sc) or sc == np.inf else np.inf
-        return out
+        fold_of = np.full((len(candidates), len(_y)), -1, dtype=np.int8)
+        for c, folds in enumerate(fold_sets):
+            for k, f in enumerate(folds):
+                fold_of[c, np.asarray(f, dtype=np.int64)] = k
+        rows = [gp.full_hyper(hp) for hp in candidates]
+        return _cv_scores(gp, rows, fold_of, k_folds, _y, dev, inv, scoring, weighted_mse_method, weighted_mse_factor, batch).tolist()
     finally:
         if own:
             batch.close()
@@ -183,29 +246,44 @@ def _evaluate_candidate(hyperparams, gp, _theta, _y, y_scaler, k_folds, scoring,
     return cv_fold_scores(gp, [hyperparams], [kfold_splits(len(_theta), k_folds, rng)], _theta, _y, y_scaler, scoring, **kw)[0]
 
 
-def _mean_scores(cands, gp, _theta, _y, y_scaler, k_folds, scoring, rng, batch=None, ranks=None, **kw):
+def _mean_scores(cands, gp, _theta, _y, y_scaler, k_folds, scoring, rng, batch=None, ranks=None, weighted_mse_method="exponential",
+                 weighted_mse_factor=1.0):
     """Mean fold score per candidate.  The fold permutations are drawn first, in candidate order (the random stream is the
     same as when the candidates are evaluated one after the other), then ALL (candidate, fold) jobs of the stage go to one
     batched call.  ``ranks=(rank, world)``: this process evaluates candidates rank, rank + world, ... only (the caller
     combines the partial score vectors: np.inf elsewhere)."""
     from .gp import _to_dev
+    from .gp_batch import HipGPBatch
     out = np.full(len(cands), np.inf)
     n = len(_theta)
-    inv = _inverse_map(y_scaler)
-    dev = (_to_dev(np.ascontiguousarray(_theta, dtype=np.float64), 2), _to_dev(np.ascontiguousarray(_y, dtype=np.float64)))
-    sel, fold_sets = [], []
+    _y = np.asarray(_y, dtype=np.float64).ravel()
+    if k_folds > 127:
+        raise ValueError("k_folds must be <= 127")
+    # sklearn's KFold(shuffle=True): one shuffle of arange(n) cut into k consecutive pieces, the first n % k one longer
+    pattern = np.repeat(np.arange(k_folds, dtype=np.int8), [n // k_folds + (1 if q < n % k_folds else 0) for q in range(k_folds)])
+    sel, perms = [], []
     for i, hp in enumerate(cands):
         if not np.all(np.isfinite(hp)):
             continue
-        folds = kfold_splits(n, k_folds, rng)                 # drawn for EVERY finite candidate: the stream does not depend on `ranks`
+        perm = rng.permutation(n)                             # drawn for EVERY finite candidate: the stream does not depend on `ranks`
         if ranks is not None and i % ranks[1] != ranks[0]:
             continue
-        sel.append(i); fold_sets.append(folds)
+        sel.append(i); perms.append(perm)
     if not sel:
         return out
-    scores = cv_fold_scores(gp, [cands[i] for i in sel], fold_sets, _theta, _y, y_scaler, scoring, batch=batch, dev=dev, inv=inv, **kw)
+    fold_of = np.empty((len(sel), n), dtype=np.int8)
+    np.put_along_axis(fold_of, np.asarray(perms, dtype=np.int64), pattern[None, :], axis=1)
+    dev = (_to_dev(np.ascontiguousarray(_theta, dtype=np.float64), 2), _to_dev(np.ascontiguousarray(_y, dtype=np.float64)))
+    own = batch is None
+    if own:
+        batch = HipGPBatch(gp.ndim, gp.kernel_name)
+    try:
+        scores = _cv_scores(gp, [gp.full_hyper(cands[i]) for i in sel], fold_of, k_folds, _y, dev, _inverse_map(y_scaler), scoring,
+                            weighted_mse_method, weighted_mse_factor, batch)
+    finally:
+        if own:
+            batch.close()
     for i, s in zip(sel, scores):
-        s = np.asarray(s, dtype=np.float64)
         ok = s[np.isfinite(s)]
         if len(ok):
             out[i] = np.mean(ok)

@@ -147,6 +147,9 @@ int alabi_gp_grad_log_likelihood(alabi_gp* gp, double* grad_out, void* stream);
 int alabi_gp_get_alpha(alabi_gp* gp, double* alpha_out /* [N] */, void* stream);
 int alabi_gp_get_factor(alabi_gp* gp, double* L_out /* [N,N] row-major, upper part zero */,
                         void* stream);
+/* gp.solver.get_inverse() -- alabi/utility.py:610 (the finite-difference acquisition gradient): K^-1 [N,N] row-major, both
+ * triangles, = W^T W on the matrix cores from the cached W = L^-1 of the current factor (built on demand). */
+int alabi_gp_get_inverse(alabi_gp* gp, double* Kinv_out, void* stream);
 int alabi_gp_n(alabi_gp* gp, int* n /* host */);
 
 /* kernel.get_value(x1, x2) -- alabi/utility.py:549, :607.  K_out is [n1,n2] row-major,

@@ -92,12 +92,20 @@ def _single_list(lib, nb):
     return [(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]) for q in range(n)]
 
 
+def _batch_matrix_list(lib, nb):
+    n = lib.alabi_debug_chol_batch_matrix_tasks(nb, None, 0)
+    buf = (ctypes.c_int * (4 * n))()
+    assert lib.alabi_debug_chol_batch_matrix_tasks(nb, buf, n) == n
+    return [(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]) for q in range(n)]
+
+
 def _debug_lib():
     from alabi_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build()
     lib = ctypes.CDLL(_lib.LIB_PATH)
     lib.alabi_debug_chol_tasks.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    lib.alabi_debug_chol_batch_matrix_tasks.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
     lib.alabi_debug_chol_batch_tasks.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int,
                                                  ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     return lib
@@ -135,15 +143,35 @@ def test_cholesky_task_list_default_switches_and_update4(nb, update4, monkeypatc
     _replay_cholesky_tasks(tasks, nb)
 
 
+@pytest.mark.parametrize("gk", [1, 2, 3, 4, 8, 12, 16, 255])
+@pytest.mark.parametrize("update4", ["0", "1"])
+def test_batched_cholesky_matrix_list_is_a_topological_order(gk, update4, monkeypatch):
+    """The list of ONE matrix inside a batch (chol_build_tasks_batch: full groups while the chain is far, one catch-up task per
+    tile, left-looking for gk >= nb): the same host replay -- inputs produced by earlier tasks, every block column exactly once and
+    in order on every tile."""
+    lib = _debug_lib()
+    monkeypatch.setenv("ALABI_BATCH_GK", str(gk))
+    monkeypatch.setenv("ALABI_CHOL_UPDATE4", update4)
+    monkeypatch.delenv("ALABI_BATCH_LEFT", raising=False)
+    for nb in (1, 2, 3, 4, 5, 7, 12, 13, 16, 25, 26, 40, 79):
+        tasks = _batch_matrix_list(lib, nb)
+        _replay_cholesky_tasks(tasks, nb)
+        if gk >= nb:                                     # left-looking: every tile that takes updates is written by ONE task
+            tiles = sum({2: 1, 4: 2, 5: 4}[t[0] & 255] for t in tasks if (t[0] & 255) >= 2)
+            assert tiles == (nb - 1) * (nb - 2) // 2 + max(nb - 2, 0)     # (i, j) with i > j >= 1, and the diagonal tiles from (2, 2) on
+
+
+@pytest.mark.parametrize("left", ["1", "0"])
 @pytest.mark.parametrize("nlists,window", [(1, 0), (1, 3), (3, 2), (8, 3), (8, 0), (8, 100)])
-def test_batched_cholesky_queue_keeps_every_matrix_in_order(nlists, window, monkeypatch):
+def test_batched_cholesky_queue_keeps_every_matrix_in_order(nlists, window, left, monkeypatch):
     """The interleaved queue of the batched factorisation (alabi/gp_utils.py:511-700: candidates x folds): every matrix lives in
     exactly one list, its tasks appear there in the order of its own single-matrix list (so each list is a topological order and a
     workgroup only waits for tasks in front of the one it drew), nothing is lost or duplicated -- for mixed sizes, any number of
     lists and any stagger."""
     lib = _debug_lib()
-    for k in ("ALABI_CHOL_GK", "ALABI_CHOL_NEAR", "ALABI_CHOL_W8", "ALABI_CHOL_UPDATE2", "ALABI_CHOL_UPDATE4"):
+    for k in ("ALABI_CHOL_GK", "ALABI_CHOL_NEAR", "ALABI_CHOL_W8", "ALABI_CHOL_UPDATE2", "ALABI_CHOL_UPDATE4", "ALABI_BATCH_GK"):
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("ALABI_BATCH_LEFT", left)
     nbs = [25, 25, 26, 3, 25, 16, 40, 25, 1, 5, 25, 2, 33, 25, 25, 7, 25]
     B = len(nbs)
     arr = (ctypes.c_int * B)(*nbs)
@@ -162,5 +190,7 @@ def test_batched_cholesky_queue_keeps_every_matrix_in_order(nlists, window, monk
             per_matrix[b].append((t & 0xFFFF, buf[4 * x + 1], buf[4 * x + 2], buf[4 * x + 3]))
     assert sorted(home) == list(range(B))
     for b in range(B):
-        assert per_matrix[b] == _single_list(lib, nbs[b])     # the single-matrix order, task for task
+        assert per_matrix[b] == _batch_matrix_list(lib, nbs[b])     # the matrix's own order, task for task
+        if left == "0":
+            assert per_matrix[b] == _single_list(lib, nbs[b])
         _replay_cholesky_tasks(per_matrix[b], nbs[b])

@@ -467,6 +467,56 @@ def test_grad_utilities_against_reference_vectors(torch_gpu, golden_grad):
     assert np.max(np.abs(bape[ok] - g["grad_bape"][ok]) / (np.abs(g["grad_bape"][ok]) + 1.0)) <= 1e-5
 
 
+@pytest.mark.parametrize("N,d,log_wn", [(130, 3, -12.0), (1000, 6, -10.0), (64, 2, -8.0), (1999, 10, -12.0)])
+def test_get_inverse_is_native_and_matches_cho_solve(torch_gpu, N, d, log_wn):
+    """gp.solver.get_inverse() (reference: alabi/utility.py:610) = alabi_gp_get_inverse (K^-1 = W^T W on the matrix cores):
+    symmetric, K K^-1 = I to rounding x condition, and equal to scipy's cho_solve(L, I) of the oracle within the same bound."""
+    from alabi_amd import HipGP
+    from oracle.gp_oracle import OracleGP
+    X, y, h = make_problem(N, d, 40 + d, log_wn=log_wn)
+    g = HipGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+    o = OracleGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X)
+    Kinv = g.solver.get_inverse()
+    assert Kinv.shape == (N, N) and np.array_equal(Kinv, Kinv.T)
+    K = o.get_matrix(X)
+    Kinv_o = o.get_inverse()
+    # both inverses carry an error of order eps * cond(K) * |K^-1|: compare residuals, and each other within that bound
+    eps_cond = np.finfo(float).eps * np.linalg.cond(K)
+    res = np.max(np.abs(K @ Kinv - np.eye(N)))
+    res_o = np.max(np.abs(K @ Kinv_o - np.eye(N)))
+    assert res <= max(20.0 * res_o, 1e-9), (res, res_o)
+    assert np.max(np.abs(Kinv - Kinv_o)) <= 50.0 * eps_cond * np.max(np.abs(Kinv_o)), (eps_cond,)
+    # quadratic forms (what the reference's variance gradient takes): k^T K^-1 k against the variance of the predict path
+    Xs = np.random.RandomState(3).uniform(-2.5, 2.5, (5, d))
+    ks = g.kernel.get_value(Xs, X)
+    _, var = g.predict(y, Xs, return_var=True)
+    amp = np.exp(h["log_amp"])
+    assert np.max(np.abs((amp - np.einsum("qi,ij,qj->q", ks, Kinv, ks)) - var)) <= 1e-6 * amp
+
+
+def test_reference_finite_difference_gradients_through_native_get_inverse(torch_gpu, golden_grad):
+    """The reference's finite-difference route for d var / dx (utility.py:586-623: numerical_kernel_gradient + solver.get_inverse(),
+    restated in oracle/utility_oracle.py) run on the HipGP protocol members -- kernel.get_value, solver.get_inverse, _x, _alpha --
+    against the arrays the reference's own functions returned on george-free inputs (tests/golden/make_golden_grad.py)."""
+    from alabi_amd import HipGP
+    from oracle import utility_oracle as uo
+    g = golden_grad
+    gp = HipGP(g["grad_X"].shape[1], float(g["grad_mean"]), float(g["grad_log_wn"]), float(g["grad_log_amp"]), g["grad_log_M"])
+    gp.compute(g["grad_X"])
+    gp.predict(g["grad_y"], g["grad_X"][:1], return_cov=False)
+
+    class Protocol:                                          # the members the oracle's restatement touches, served by HipGP
+        _x = gp._x
+        _alpha = gp._alpha
+        _k = staticmethod(lambda a, b: gp.kernel.get_value(a, b))
+        get_inverse = staticmethod(gp.solver.get_inverse)
+    th = g["grad_theta"][:8]
+    dvar = np.array([uo.grad_gp_var_prediction(t, Protocol) for t in th])
+    dmu = np.array([uo.grad_gp_mean_prediction(t, Protocol) for t in th])
+    assert np.max(np.abs(dmu - g["grad_dmu"][:8])) <= 1e-6 * np.max(np.abs(g["grad_dmu"]))
+    assert np.max(np.abs(dvar - g["grad_dvar"][:8])) <= 1e-5 * np.max(np.abs(g["grad_dvar"]))
+
+
 @pytest.mark.parametrize("N,d,M", [(200, 3, 2048 + 37), (1000, 10, 4096), (777, 5, 20001), (2000, 10, 40000)])
 def test_two_wave_variance_kernel(N, d, M, monkeypatch):
     """predict_var_w2_kernel (128 queries per workgroup, two MFMA waves per SIMD; taken from 2048 queries on) against the

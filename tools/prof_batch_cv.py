@@ -23,7 +23,12 @@ for b in range(B):
     val.append(np.sort(folds[k])); train.append(np.sort(np.concatenate([folds[q] for q in range(5) if q != k]))); hyper.append(row)
 hyper = np.array(hyper)
 Xd, yd = torch.as_tensor(X, device="cuda"), torch.as_tensor(y, device="cuda")
+torch.cuda.synchronize(); t0 = time.perf_counter()
 bt = HipGPBatch(d)
+bt.fit_predict(Xd, yd, hyper[:5], train[:5], val[:5]); torch.cuda.synchronize(); t1 = time.perf_counter()
+bt.fit_predict(Xd, yd, hyper, train, val); torch.cuda.synchronize(); t2 = time.perf_counter()
+bt.fit_predict(Xd, yd, hyper, train, val); torch.cuda.synchronize(); t3 = time.perf_counter()
+print(f"first call with 5 jobs (handle, module load) {1e3 * (t1 - t0):.1f} ms; first call with {B} jobs (workspace, task list) {1e3 * (t2 - t1):.1f} ms; second {1e3 * (t3 - t2):.1f} ms", flush=True)
 N = len(train[0])
 flops = B * N ** 3 / 3.0
 
@@ -41,18 +46,27 @@ def run(tag, reps=3):
     return ll, mu
 
 
-settings = [(8, 3)]
+settings = [(8, 8, None, None, None)]
 if sweep:
-    settings = [(8, 3), (8, 2), (8, 4), (8, 6), (8, 0), (1, 16), (1, 24), (1, 0), (4, 4), (2, 8)]
+    settings = [(8, w, gk, None, "1") for gk in (6, 8, 10, 12) for w in (0, 6, 8, 12, 16)]
 ref = None
-for lists, window in settings:
+for lists, window, gk, near, u4 in settings:
     os.environ["ALABI_BATCH_LISTS"], os.environ["ALABI_BATCH_WINDOW"] = str(lists), str(window)
-    ll, mu = run(f"lists={lists} window={window}")
+    os.environ["ALABI_BATCH_LEFT"] = "0" if gk == "left0" else "1"
+    for k, v in (("ALABI_BATCH_GK", gk), ("ALABI_CHOL_NEAR", near), ("ALABI_CHOL_UPDATE4", u4)):
+        if v is None or v == "left0":
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    ll, mu = run(f"lists={lists} window={window} gk={gk} near={near} update4={u4}")
     if ref is None:
         ref = (ll.copy(), mu.clone())
     else:
         assert np.array_equal(ll, ref[0]) and torch.equal(mu, ref[1]), "results depend on the queue order"
-os.environ.pop("ALABI_BATCH_LISTS"); os.environ.pop("ALABI_BATCH_WINDOW")
+for k in ("ALABI_BATCH_LISTS", "ALABI_BATCH_WINDOW", "ALABI_BATCH_GK", "ALABI_BATCH_LEFT", "ALABI_CHOL_NEAR", "ALABI_CHOL_UPDATE4"):
+    os.environ.pop(k, None)
+if sweep:
+    sys.exit(0)
 os.environ["ALABI_BATCH_QUEUE"] = "0"
 if B <= 100:
     run("launch-per-step fallback", reps=1)
