@@ -78,6 +78,7 @@ SIGNATURES = {
     "alabi_dist_comm_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "alabi_dist_comm_create_callback": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "alabi_dist_comm_destroy": (_i, [_vp]),
+    "alabi_dist_comm_stats": (_i, [_vp, _pll]),
     "alabi_ens_run_sharded": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _i, _d, _vp, _vp, _vp, _vp]),
     "alabi_ens_step_lists": (_i, [_vp, _i, _vp, _pi, _vp]),
     "alabi_ens_step_with_randoms": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp]),

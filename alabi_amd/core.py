@@ -533,12 +533,20 @@ class SurrogateModel(object):
                     cands[0] = self.get_hyperparameter_vector(self.gp)
                 if self.uniform_scales:
                     cands = np.array([self.expand_hyperparameter_vector(c) for c in cands])
+                # several ranks (one process per GPU, torch.distributed initialised) and multi_proc: the candidates of every
+                # stage are dealt over the ranks -- the reference maps them over its process pool (gp_utils.py:640-700) -- and the
+                # partial score vectors (+inf elsewhere) are combined with one MIN all-reduce; every rank then picks the same winner
+                from . import dist as adist
+                rank, world = adist.world_info()
+                shard_kw = {}
+                if world > 1 and multi_proc:
+                    shard_kw = dict(ranks=(rank, world), reduce_scores=lambda sc: adist.allreduce_array(sc, "min"))
                 op_gp = gp_utils.optimize_gp_kfold_cv(
                     self.gp, _theta, _y, cands, self.y_scaler, k_folds=cv_folds, scoring=cv_scoring,
                     stage2_candidates=cv_stage2_candidates, stage2_width=cv_stage2_width,
                     stage3_candidates=cv_stage3_candidates, stage3_width=cv_stage3_width,
                     weighted_mse_method=cv_weighted_mse_method, weighted_mse_factor=cv_weighted_factor,
-                    verbose=self.verbose, random_state=self._seed())
+                    verbose=self.verbose, random_state=self._seed(), **shard_kw)
             except Exception as e:  # noqa: BLE001
                 print(f"Warning: CV hyperparameter optimization failed: {e}")
                 op_gp = None
@@ -657,15 +665,42 @@ class SurrogateModel(object):
             hi = torch.as_tensor(self._bounds[:, 1], device=_dev())
             cand = lo + (hi - lo) * torch.rand((ncand, self.ndim), dtype=torch.float64, device=_dev(), generator=gen)
             nref, nper, ntop = int(kw.get("refine", 4)), int(kw.get("nrefine", 4096)), int(kw.get("ntop", 32))
-            out = ut.utility_scan(self.gp, self._y, cand, self._bounds, algorithm=self.algorithm, y_best=y_best,
-                                  return_all=nref > 0)
-            _thetaN, u_best, idx = out[:3]
+            from . import dist as adist
+            rank, world = adist.world_info()
+            if world > 1 and getattr(self, "allow_opt_multiproc", True) and ncand >= world:
+                # several ranks: every rank holds the same GP and draws the same candidates; it scores ITS contiguous slice, one
+                # (value, index) pair and the slices' best `ntop` are exchanged, and every rank goes on from the same incumbent
+                # and the same centres (BASELINE config C5: 1e6 candidates over 8 GPUs).  The reference
+                # spreads its scipy restarts over a process pool instead (alabi/utility.py:1030-1163, allow_opt_multiproc).
+                b0, e0 = adist.slice_bounds(ncand, world, rank)
+                out = ut.utility_scan(self.gp, self._y, cand[b0:e0], self._bounds, algorithm=self.algorithm, y_best=y_best,
+                                      return_all=nref > 0)
+                gi_local = b0 + int(out[2]) if out[2] >= 0 and np.isfinite(out[1]) else -1
+                u_best, idx = adist.reduce_min_index(out[1] if gi_local >= 0 else np.inf, gi_local)
+                _thetaN = cand[idx].cpu().numpy() if idx >= 0 else np.nan
+                centers = None
+                if idx >= 0 and nref > 0:
+                    u_loc = torch.where(torch.isfinite(out[3]), out[3], torch.full_like(out[3], float("inf")))
+                    kk = min(ntop, e0 - b0)
+                    top = torch.topk(-u_loc, kk)
+                    mine = np.full((ntop, 2), [np.inf, -1.0])
+                    mine[:kk, 0] = (-top.values).cpu().numpy()
+                    mine[:kk, 1] = (top.indices + b0).cpu().numpy()
+                    allp = adist.allgather_rows(mine)
+                    allp = allp[allp[:, 1] >= 0]
+                    keep = allp[np.lexsort((allp[:, 1], allp[:, 0]))][:min(ntop, ncand)]      # ascending value, ties to the lower index
+                    centers = cand[torch.as_tensor(keep[:, 1].astype(np.int64), device=_dev())]
+            else:
+                out = ut.utility_scan(self.gp, self._y, cand, self._bounds, algorithm=self.algorithm, y_best=y_best,
+                                      return_all=nref > 0)
+                _thetaN, u_best, idx = out[:3]
+                centers = None
+                if idx >= 0 and nref > 0:
+                    u_all = torch.where(torch.isfinite(out[3]), out[3], torch.full_like(out[3], float("inf")))
+                    centers = cand[torch.topk(-u_all, min(ntop, ncand)).indices]
             # Zoom stages (stand in for the reference's local optimiser, utility.py:1030-1163, at batched-scan cost):
             # Gaussian clouds of shrinking width around the best candidates so far, scored in one pass each.
             if idx >= 0 and nref > 0:
-                u_all = torch.where(torch.isfinite(out[3]), out[3], torch.full_like(out[3], float("inf")))
-                k = min(ntop, ncand)
-                centers = cand[torch.topk(-u_all, k).indices]
                 width = 0.08 * (hi - lo)
                 for _ in range(nref):
                     rep = centers[torch.randint(0, centers.shape[0], (nper,), device=_dev(), generator=gen)]
@@ -731,6 +766,7 @@ class SurrogateModel(object):
         self.gp_opt_freq = gp_opt_freq
         self.obj_opt_method = obj_opt_method
         self.use_grad_opt = bool(use_grad_opt)
+        self.allow_opt_multiproc = bool(allow_opt_multiproc)    # several ranks: shard the candidate scan of find_next_point
         res = self.training_results
         first_iter = res["iteration"][-1] if len(res["iteration"]) else 0
         if self.verbose:
@@ -884,8 +920,23 @@ class SurrogateModel(object):
           does the accept test (alabi_ens_propose / alabi_ens_accept).
         * ``like_fn="true"`` or a callable, or scalers that are neither of the above: the same split with the
           likelihood evaluated on the host as well (walkers then move in the original theta coordinates).
-        ``opt_init=True`` starts the walkers around ``find_map()``.  ``multi_proc`` / ``ncore`` are accepted for
-        signature compatibility: there is no process pool, the parallel axis is the GPU."""
+        ``opt_init=True`` starts the walkers around ``find_map()``.
+
+        Several GPUs (the reference's parallel axis is a process pool handed to emcee, core.py:2300, :2322, built at :349-369;
+        ``ncore`` / ``pool_method`` have no meaning here): run one process per GPU under ``torch.distributed`` (e.g.
+        ``python -m torch.distributed.run --nproc-per-node 8 script.py``, backend "nccl" = RCCL) and have every rank make the
+        same calls.  With ``multi_proc=True`` and more than one rank
+          * default -- REPLICAS: every rank runs its own ensemble of ``nwalkers`` walkers (sampler seed + rank, its own start
+            points), no communication inside the run; after each run the flattened samples of all ranks are concatenated on
+            every rank (``emcee_samples`` is identical everywhere) and ``min_ess`` counts the samples of all ranks;
+          * ``sampler_kwargs={"shard": True}`` -- ONE ensemble whose active half is partitioned over the ranks, an RCCL
+            all-gather of the new walker rows per half step (alabi_amd.dist.ShardedRun); every rank holds the same chain.
+        Files (the .npz of samples, the cached model) are written by rank 0 only."""
+        from . import dist as adist
+        rank, world = adist.world_info()
+        sampler_kwargs = dict(sampler_kwargs)
+        shard = bool(sampler_kwargs.pop("shard", False)) and bool(multi_proc) and world > 1
+        replicas = bool(multi_proc) and world > 1 and not shard
         # ---- likelihood
         like_host = None                          # host callable on theta [n,d] -> [n], or None for the device surrogate
         if like_fn is None or (isinstance(like_fn, str) and like_fn.lower() in ("surrogate", "gp")):
@@ -972,10 +1023,15 @@ class SurrogateModel(object):
         self.nsteps = int(nsteps)
         if hasattr(self, "gp") and len(self.training_results["iteration"]) > 0:
             self.eval_gp_at_iteration(-1)   # makes self.gp carry the latest hyper-parameters / data
+        if shard and (prior_host is not None or like_host is not None):
+            raise ValueError('sampler_kwargs={"shard": True} needs the fused log-probability (surrogate likelihood, shipped priors '
+                             'and scalers); host callables run as replicas')
         if opt_init:
             p0 = self.find_map(prior_fn=self.prior_fn)           # core.py:2290-2292
         else:
-            p0 = ut.prior_sampler(nsample=self.nwalkers, bounds=box, sampler="uniform", random_state=self._seed())
+            p0_seed = self._seed()                               # (drawn on every rank alike: the model's stream stays in step)
+            p0 = ut.prior_sampler(nsample=self.nwalkers, bounds=box, sampler="uniform",
+                                  random_state=p0_seed + (1000003 * rank if replicas else 0))
         p0 = p0 * t_mult + t_add                   # walkers live in scaled coordinates
         if hasattr(self, "gp"):
             gp_obj, y_obj = self.gp, self._y
@@ -986,6 +1042,10 @@ class SurrogateModel(object):
         all_chains, all_times, accumulated, run_number = [], [], 0, 1
         kw = dict(sampler_kwargs)
         kw.setdefault("seed", self._seed())
+        if replicas:
+            kw["seed"] = int(kw["seed"]) + rank
+        if shard:
+            kw["shard"] = True
         while True:
             t0 = time.time()
             self.emcee_sampler = EnsembleSampler(self.nwalkers, self.ndim, gp_obj, y_obj, _box, logp_affine=logp_affine,
@@ -996,6 +1056,8 @@ class SurrogateModel(object):
             cur_burn = burn if burn is not None else cur_iburn
             cur_thin = thin if thin is not None else cur_ithin
             cur = to_theta(self.emcee_sampler.get_chain(discard=cur_burn, thin=cur_thin, flat=True))
+            if replicas:
+                cur = adist.gather_replicas(cur)                 # every rank's kept samples, in rank order, on every rank
             all_chains.append(cur)
             accumulated += cur.shape[0]
             if self.verbose and min_ess > 0:
@@ -1007,7 +1069,7 @@ class SurrogateModel(object):
                 print(f"WARNING: Reached maximum of 10 runs, stopping with {accumulated} samples")
                 break
             p0 = self.emcee_sampler.get_last_sample().coords
-            kw["seed"] = self._seed()
+            kw["seed"] = self._seed() + (rank if replicas else 0)
         self.emcee_samples = np.vstack(all_chains) if len(all_chains) > 1 else all_chains[0]
         self.emcee_samples_full = to_theta(self.emcee_sampler.get_chain())
         self.iburn, self.ithin = cur_iburn, cur_ithin
@@ -1019,11 +1081,18 @@ class SurrogateModel(object):
             self.emcee_samples_gp = self.emcee_samples
         self.acc_frac = np.mean(self.emcee_sampler.acceptance_fraction)
         self.autcorr_time = np.mean(self.emcee_sampler.get_autocorr_time(tol=0))
+        if replicas:                                             # the same numbers on every rank: the mean over the ensembles
+            both = adist.allreduce_array([self.acc_frac, self.autcorr_time], "sum") / world
+            self.acc_frac, self.autcorr_time = float(both[0]), float(both[1])
+        self.emcee_ranks = world if (replicas or shard) else 1
+        self.emcee_mode = "replicas" if replicas else ("sharded" if shard else "single")
         if self.verbose:
             print(f"Total samples: {self.emcee_samples.shape[0]}")
             print("Mean acceptance fraction: {0:.3f}".format(self.acc_frac))
             print("Mean autocorrelation time: {0:.3f} steps".format(self.autcorr_time))
         self.emcee_run = True
+        if (replicas or shard) and rank != 0:
+            return                                               # files are rank 0's
         if self.cache:
             try:
                 self.save()

@@ -460,6 +460,7 @@ int alabi_ens_create(alabi_gp* gp, int W, int d, int n_ensembles, const double* 
     alabi_ens* e = new (std::nothrow) alabi_ens();
     if (!e) return ALABI_BAD_ARGUMENT;
     e->gp = gp; e->W = W; e->d = d; e->E = n_ensembles; e->seed = seed;
+    { static std::atomic<long long> next_serial{0}; e->serial = ++next_serial; }
     for (int k = 0; k < ALABI_MAX_DIM; ++k) {
         e->lo[k] = (k < d) ? bounds[2 * k] : 0.0;
         e->hi[k] = (k < d) ? bounds[2 * k + 1] : 0.0;
@@ -546,6 +547,7 @@ int alabi_ens_set_normal_prior(alabi_ens* e, const double* mean, const double* s
         }
     }
     e->consts_gen = -1;                                                  // re-upload
+    e->settings_gen++;
     if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
     return ALABI_OK;
 }
@@ -553,6 +555,7 @@ int alabi_ens_set_normal_prior(alabi_ens* e, const double* mean, const double* s
 int alabi_ens_set_logp_affine(alabi_ens* e, double scale, double shift) {
     if (!e || !(scale > 0.0) || !std::isfinite(scale) || !std::isfinite(shift)) return ALABI_BAD_ARGUMENT;
     e->lp_scale = scale; e->lp_shift = shift;
+    e->settings_gen++;
     if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }   // captured launches carry the old values
     return ALABI_OK;
 }
@@ -560,6 +563,7 @@ int alabi_ens_set_logp_affine(alabi_ens* e, double scale, double shift) {
 int alabi_ens_set_logp_map(alabi_ens* e, int kind) {
     if (!e || kind < 0 || kind > 2) return ALABI_BAD_ARGUMENT;
     e->ymap = kind;
+    e->settings_gen++;
     if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }   // captured launches carry the old value
     return ALABI_OK;
 }
@@ -568,6 +572,7 @@ int alabi_ens_set_stream(alabi_ens* e, int enabled) {
     if (!e) return ALABI_BAD_ARGUMENT;
     if (enabled && !(e->hist && e->err)) return ALABI_BAD_ARGUMENT;
     e->stream_ok = enabled ? 1 : 0;
+    e->settings_gen++;
     return ALABI_OK;
 }
 
@@ -684,7 +689,8 @@ int alabi_ens_run(alabi_ens* e, double* coords, double* logp, long long step0, l
     // ens_stream_kernel takes ceil(W/2 / stream_grid) proposals per workgroup one after the other (2.0 / 3.7 / 7.1 us per half step at
     // 1 / 2 / 4 of them, N = 2000); from four on the group kernel is ahead (5.3 us at W = 2048: 1.9e8 against 1.4e8 samples/s)
     const bool crowded = can_stream && e->stream_grid > 0 && ((e->W + 1) / 2 + e->stream_grid - 1) / e->stream_grid >= 4;
-    const bool use_group = e->stream_ok && s != nullptr && !group_off && (group_pref || !can_stream || crowded) && ens_group_fits(e);
+    const bool use_group = e->stream_ok && s != nullptr && !group_off && (group_pref || !can_stream || crowded) && ens_group_fits(e) &&
+                           ens_group_buffers(e, s);
     if (e->stream_ok && s != nullptr && (can_stream || use_group)) {
         e->last_path = use_group ? 3 : 1;
         ALABI_HIP_CHECK(hipMemsetAsync(e->err, 0, sizeof(int), s));

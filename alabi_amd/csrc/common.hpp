@@ -159,6 +159,8 @@ struct alabi_ens {
     size_t part_words = 0;
     unsigned long long* cand = nullptr;  // [2 chunk_cap][E][n0][2 d + 4] candidate rows (proposal, old coordinates, logp, ln factors, prior)
     size_t cand_words = 0;
+    long long settings_gen = 0;          // bumped by every setter that changes what captured launches carry (graph keys)
+    long long serial = 0;                // unique per handle for the life of the process (a new handle at an old address is not the old one)
     int group_plan[8] = {0};  // blocking of the last group-kernel launch: Q, G, NG, RT, tpm, ltw, KS, LDS bytes (alabi_ens_group_plan)
 };
 
@@ -264,6 +266,7 @@ int launch_ens_stream(alabi_ens* e, double* coords, double* logp, int K, int thi
                       long long* n_accept, hipStream_t s);
 // ens_group.hip
 bool ens_group_fits(const alabi_ens* e);
+bool ens_group_buffers(alabi_ens* e, hipStream_t s);   // the group kernel's hand-off buffers exist (allocates on first use); false: take another path
 int launch_ens_group(alabi_ens* e, double* coords, double* logp, int K, int thin_by, double* chain, double* chain_logp,
                      long long* n_accept, hipStream_t s);
 int launch_ens_hist_prologue(alabi_ens* e, double* coords, double* logp, int K, bool fill, hipStream_t s);

@@ -603,14 +603,21 @@ struct GroupPlan {
 };
 #define ALABI_GRP_RT 5                           // point tiles per wave held in registers by the G8 instantiations
 
+#define ALABI_GRP_MAX_DEV 64                     // per-device caches (a process may touch several devices)
+static int group_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev >= 0 && dev < ALABI_GRP_MAX_DEV ? dev : 0;
+}
 static int group_n_cu() {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    static int n_cu[ALABI_GRP_MAX_DEV] = {0};
+    const int dev = group_device();
+    if (n_cu[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu[dev] = v;
     }
-    return n_cu;
+    return n_cu[dev];
 }
 
 // G members per group: 8 for d <= 14 (rows of <= 16 words); for wider rows 8 with four point tiles per wave in registers when the
@@ -653,6 +660,25 @@ static GroupPlan group_plan(const alabi_ens* e) {
 
 bool ens_group_fits(const alabi_ens* e) { return e->hist && e->err && group_plan(e).ok; }
 
+// The hand-off buffers of the group kernel (partial sums, candidate rows) for a full chunk: allocated on first use, ~0.3 GB at C4
+// and ~0.9 GB at the C5 size.  false = the blocking does not fit the 32-bit word offsets of the link records or the memory is not
+// there -- alabi_ens_run then takes another path (ens_stream_kernel or one launch per half step) instead of failing.
+bool ens_group_buffers(alabi_ens* e, hipStream_t s) {
+    const GroupPlan pl = group_plan(e);
+    if (!pl.ok) return false;
+    const int n0 = (e->W + 1) / 2, CW = 2 * e->d + 4;
+    const size_t part_per_half = (size_t)e->E * pl.NG * pl.QP * pl.G, cand_per_half = (size_t)e->E * n0 * CW;
+    if (2 * (size_t)e->chunk_cap * part_per_half > 0x7fffffffull || 2 * (size_t)e->chunk_cap * cand_per_half > 0x7fffffffull) return false;
+    auto ensure = [&](unsigned long long** p, size_t* have, size_t need) {
+        if (*have >= need) return true;
+        if (*p) { (void)hipStreamSynchronize(s); (void)hipFree(*p); *p = nullptr; *have = 0; }
+        if (hipMalloc(p, need * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
+        *have = need;
+        return true;
+    };
+    return ensure(&e->part, &e->part_words, 2 * e->chunk_cap * part_per_half) && ensure(&e->cand, &e->cand_words, 2 * e->chunk_cap * cand_per_half);
+}
+
 __global__ void __launch_bounds__(256)
 ens_group_fill_kernel(unsigned long long* __restrict__ h, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) h[i] = ALABI_GRP_EMPTY;
@@ -687,11 +713,11 @@ static int group_launch(const GroupArgs& a, const GroupPlan& pl, int E, hipStrea
         constexpr bool HAS_RT = (KS > 4) || (Q <= 2);        // instantiations with register-resident tiles
         const void* kern = (pl.RT > 0 && HAS_RT) ? reinterpret_cast<const void*>(ens_group_kernel<KS, Q, (KS > 4), (HAS_RT ? ALABI_GRP_RT : 0), GENERIC>)
                                                  : reinterpret_cast<const void*>(ens_group_kernel<KS, Q, false, 0, GENERIC>);
-        static bool attr_set[2] = {false, false};            // per instantiation of this function, per variant
-        const int var = (pl.RT > 0 && HAS_RT) ? 1 : 0;
-        if (!attr_set[var]) {
+        static bool attr_set[ALABI_GRP_MAX_DEV][2] = {};    // per instantiation of this function: per device, per variant
+        const int var = (pl.RT > 0 && HAS_RT) ? 1 : 0, dev = group_device();
+        if (!attr_set[dev][var]) {
             ALABI_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set[var] = true;
+            attr_set[dev][var] = true;
         }
         GroupArgs args = a;
         void* params[] = {&args};
@@ -709,18 +735,7 @@ int launch_ens_group(alabi_ens* e, double* coords, double* logp, int K, int thin
     if (st != ALABI_OK) return st;
     const int n0 = (e->W + 1) / 2, CW = 2 * e->d + 4;
     const size_t part_per_half = (size_t)e->E * pl.NG * pl.QP * pl.G, cand_per_half = (size_t)e->E * n0 * CW;
-    if (2 * (size_t)e->chunk_cap * part_per_half > 0x7fffffffull || 2 * (size_t)e->chunk_cap * cand_per_half > 0x7fffffffull)
-        return ALABI_BAD_ARGUMENT;                           // 32-bit word offsets in the link records
-    if (e->part_words < 2 * e->chunk_cap * part_per_half) {
-        if (e->part) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(e->part); e->part = nullptr; e->part_words = 0; }
-        ALABI_HIP_CHECK(hipMalloc(&e->part, 2 * e->chunk_cap * part_per_half * sizeof(unsigned long long)));
-        e->part_words = 2 * e->chunk_cap * part_per_half;
-    }
-    if (e->cand_words < 2 * e->chunk_cap * cand_per_half) {
-        if (e->cand) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(e->cand); e->cand = nullptr; e->cand_words = 0; }
-        ALABI_HIP_CHECK(hipMalloc(&e->cand, 2 * e->chunk_cap * cand_per_half * sizeof(unsigned long long)));
-        e->cand_words = 2 * e->chunk_cap * cand_per_half;
-    }
+    if (!ens_group_buffers(e, s)) return ALABI_BAD_ARGUMENT;   // (alabi_ens_run asks before it chooses this kernel)
     hipLaunchKernelGGL(ens_group_fill_kernel, dim3(2048), dim3(256), 0, s, e->part, 2 * K * part_per_half);
     hipLaunchKernelGGL(ens_group_fill_kernel, dim3(2048), dim3(256), 0, s, e->cand, 2 * K * cand_per_half);
     hipLaunchKernelGGL(ens_link_kernel, dim3(K, e->E), dim3(256), 0, s, e->draws, e->W, n0, pl.NG, pl.QP, pl.G, CW);

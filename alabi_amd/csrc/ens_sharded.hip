@@ -34,7 +34,21 @@ struct alabi_comm {
     double* shist = nullptr;              // [2 chunk][nranks * per][d + 2] rows by (half step, rank, slot)
     size_t shist_cap = 0;
     hipGraphExec_t graph = nullptr;       // the enqueues of one chunk
-    struct Key { void *ens, *coords, *logp; int K; double a; long long gp_gen; } key{};
+    // what the captured launches carry: the handle (by serial: a new handle at an old address is another one), its settings
+    // generation (y map, affine map, prior, block size: every setter bumps it), the buffers, the GP generation, the partition
+    struct Key {
+        long long ens_serial = 0, settings_gen = 0, gp_gen = 0;
+        void *coords = nullptr, *logp = nullptr, *draws = nullptr, *shist = nullptr;
+        double a = 0.0;
+        int K = 0, nranks = 0, rank = 0, per = 0;
+        bool operator==(const Key& o) const {
+            return ens_serial == o.ens_serial && settings_gen == o.settings_gen && gp_gen == o.gp_gen && coords == o.coords &&
+                   logp == o.logp && draws == o.draws && shist == o.shist && a == o.a && K == o.K && nranks == o.nranks &&
+                   rank == o.rank && per == o.per;
+        }
+    } key{};
+    long long n_replays = 0, n_eager = 0, n_captures = 0;   // full chunks replayed from the graph / chunks enqueued eagerly / captures
+    int failed = 0;                       // a chunk could not be enqueued: peers may be inside the collective, the communicator is dead
 };
 
 namespace alabi {
@@ -187,6 +201,12 @@ int alabi_dist_comm_create_callback(alabi_allgather_fn fn, void* user, int rank,
     return ALABI_OK;
 }
 
+int alabi_dist_comm_stats(alabi_comm* c, long long* out) {
+    if (!c || !out) return ALABI_BAD_ARGUMENT;
+    out[0] = c->n_replays; out[1] = c->n_eager; out[2] = c->n_captures; out[3] = c->failed;
+    return ALABI_OK;
+}
+
 int alabi_dist_comm_destroy(alabi_comm* c) {
     if (!c) return ALABI_OK;
     if (c->nccl && rccl().ok) (void)rccl().CommDestroy(c->nccl);
@@ -223,14 +243,12 @@ static int enqueue_sharded_chunk(alabi_ens* e, alabi_comm* c, double* coords, do
     return ALABI_OK;
 }
 
-int alabi_ens_run_sharded(alabi_ens* e, alabi_comm* c, double* coords, double* logp, long long step0, long long nsteps,
-                          int thin_by, double a, double* chain, double* chain_logp, long long* n_accept, void* stream) {
-    if (!e || !c || !coords || !logp || nsteps < 0 || thin_by < 1 || !(a > 1.0) || e->E != 1) return ALABI_BAD_ARGUMENT;
-    if (!e->gp->computed || !e->gp->has_alpha) return ALABI_NOT_COMPUTED;
-    if (nsteps == 0) return ALABI_OK;
+static int run_sharded(alabi_ens* e, alabi_comm* c, double* coords, double* logp, long long step0, long long nsteps,
+                       int thin_by, double a, double* chain, double* chain_logp, long long* n_accept, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int W = e->W, d = e->d, n0 = (W + 1) / 2, row = d + 2;
     const int per = (n0 + c->nranks - 1) / c->nranks;                    // equal slots (the larger half decides)
+    int st = ALABI_OK;
     const size_t need = (size_t)2 * e->chunk_cap * c->nranks * per * row;
     if ((size_t)2 * e->chunk_cap * c->nranks * per * row > 0x7fffffffull) return ALABI_BAD_ARGUMENT;   // 32-bit word offsets in the link records
     if (c->shist_cap < need) {
@@ -244,7 +262,6 @@ int alabi_ens_run_sharded(alabi_ens* e, alabi_comm* c, double* coords, double* l
     // of the test rig cannot
     const char* genv = getenv("ALABI_ENS_GRAPH");
     const bool want_graph = s != nullptr && !c->fn && !(genv && genv[0] == '0');
-    int st;
     if ((st = ens_sync_consts(e, s)) != ALABI_OK) return st;      // (a host copy + synchronisation: not inside a capture)
     long long done = 0;
     while (done < nsteps) {
@@ -253,8 +270,11 @@ int alabi_ens_run_sharded(alabi_ens* e, alabi_comm* c, double* coords, double* l
         // a full chunk replays the captured graph (link records, half steps, all-gathers, final state); the chain rows and the
         // counters, whose place depends on how far the run is, are gathered by one more launch behind it
         if (want_graph && K == e->chunk_cap) {
-            alabi_comm::Key key{e, coords, logp, K, a, e->gp->gen};
-            const bool same = c->graph && memcmp(&key, &c->key, sizeof(key)) == 0;
+            alabi_comm::Key key;
+            key.ens_serial = e->serial; key.settings_gen = e->settings_gen; key.gp_gen = e->gp->gen;
+            key.coords = coords; key.logp = logp; key.draws = e->draws.packed; key.shist = c->shist;
+            key.a = a; key.K = K; key.nranks = c->nranks; key.rank = c->rank; key.per = per;
+            const bool same = c->graph && key == c->key;
             if (!same) {
                 if (c->graph) { (void)hipGraphExecDestroy(c->graph); c->graph = nullptr; }
                 hipGraph_t g = nullptr;
@@ -269,7 +289,7 @@ int alabi_ens_run_sharded(alabi_ens* e, alabi_comm* c, double* coords, double* l
                     const hipError_t ie = hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0);
                     (void)hipGraphDestroy(g);
                     if (ie != hipSuccess) { (void)hipGetLastError(); c->graph = nullptr; }
-                    else c->key = key;
+                    else { c->key = key; c->n_captures++; }
                 }
             }
             if (c->graph) {
@@ -280,14 +300,30 @@ int alabi_ens_run_sharded(alabi_ens* e, alabi_comm* c, double* coords, double* l
                                        reinterpret_cast<unsigned long long*>(n_accept), coords, logp);
                     ALABI_LAUNCH_CHECK();
                 }
+                c->n_replays++;
                 done += K;
                 continue;
             }
         }
         if ((st = enqueue_sharded_chunk(e, c, coords, logp, K, thin_by, done, chain, chain_logp, n_accept, s)) != ALABI_OK) return st;
+        c->n_eager++;
         done += K;
     }
-    return ALABI_OK;
+    return st;
+}
+
+int alabi_ens_run_sharded(alabi_ens* e, alabi_comm* c, double* coords, double* logp, long long step0, long long nsteps,
+                          int thin_by, double a, double* chain, double* chain_logp, long long* n_accept, void* stream) {
+    if (!e || !c || !coords || !logp || nsteps < 0 || thin_by < 1 || !(a > 1.0) || e->E != 1) return ALABI_BAD_ARGUMENT;
+    if (!e->gp->computed || !e->gp->has_alpha) return ALABI_NOT_COMPUTED;
+    if (c->failed) { g_last_error = "this communicator failed in an earlier sharded run (a peer may still be inside the collective)"; return ALABI_HIP_ERROR; }
+    if (nsteps == 0) return ALABI_OK;
+    // A failure on ONE rank from here on leaves its peers inside (or in front of) an all-gather that will never complete: the
+    // communicator is marked dead, and the caller (alabi_amd/dist.py: ShardedRun.run) ends the process with a non-zero status
+    // instead of returning to code that would go on to other collectives.
+    const int st = run_sharded(e, c, coords, logp, step0, nsteps, thin_by, a, chain, chain_logp, n_accept, stream);
+    if (st != ALABI_OK && c->nranks > 1) c->failed = 1;
+    return st;
 }
 
 }  // extern "C"

@@ -244,15 +244,19 @@ ens_se_prepare_kernel(const double* __restrict__ Xt, const double* __restrict__ 
                       int d, int rows, double* __restrict__ Xc, double* __restrict__ h) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= Npad) return;
+    // a point that contributes nothing (padding, alpha exactly 0 or NaN) gets h = ALABI_SE_PAD AND a zero row: with its real
+    // coordinates the exponent q.x - |q|^2/2 - 1000 of se_pair_terms could still be large for a point tens of length scales from
+    // the centre (round-3 advisor), with a zero row it is -|q|^2/2 - 1000 and the term underflows to exactly 0
+    const double a = n < N ? alpha[n] : 0.0;
+    const bool live = a != 0.0 && a == a;
     double hh = 0.0;
     for (int k = 0; k < rows; ++k) {
-        const double v = (k < d && n < N) ? Xt[(size_t)k * Npad + n] - centre[k] : 0.0;
+        const double v = (k < d && live) ? Xt[(size_t)k * Npad + n] - centre[k] : 0.0;
         Xc[(size_t)k * Npad + n] = v;
         hh = fma(v, v, hh);
     }
-    const double a = n < N ? alpha[n] : 0.0;
     double out = ALABI_SE_PAD;
-    if (a != 0.0 && a == a) {
+    if (live) {
         long long bits = __double_as_longlong(0.5 * hh - log(fabs(a)));
         bits = (bits & ~1LL) | (a < 0.0 ? 1LL : 0LL);
         out = __longlong_as_double(bits);

@@ -28,7 +28,44 @@ import torch.distributed as dist
 from . import _lib
 
 __all__ = ["HipBackend", "ShardedEnsemble", "ShardedRun", "sharded_utility_scan", "reduce_min_index", "slice_bounds",
-           "gather_replicas"]
+           "gather_replicas", "world_info", "allreduce_array", "allgather_rows"]
+
+
+def world_info(group=None):
+    """(rank, world) of the initialised process group, (0, 1) without one -- what SurrogateModel consults to decide whether
+    its multi-GPU paths are on (one process per GPU, launched by torch.distributed.run)."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def _comm_device(group=None):
+    """Tensors handed to a collective live on the GPU under "nccl" (= RCCL) and on the host under "gloo" (CPU tests, and the
+    test rig with several ranks on one GPU)."""
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def allreduce_array(values, op="min", group=None):
+    """Element-wise all-reduce (min / max / sum) of a small float64 host array; returns a NumPy array, identical on every rank."""
+    v = np.ascontiguousarray(np.asarray(values, dtype=np.float64))
+    if world_info(group)[1] == 1:
+        return v.copy()
+    t = torch.as_tensor(v, device=_comm_device(group)).clone()
+    dist.all_reduce(t, op={"min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM}[op], group=group)
+    return t.cpu().numpy()
+
+
+def allgather_rows(rows, group=None):
+    """All-gather of equally shaped float64 blocks [m, c] (one per rank) -> [world * m, c] on every rank, rank order."""
+    r = np.ascontiguousarray(np.asarray(rows, dtype=np.float64))
+    world = world_info(group)[1]
+    if world == 1:
+        return r.copy()
+    dev = _comm_device(group)
+    send = torch.as_tensor(r, device=dev).reshape(-1).clone()
+    recv = torch.empty(world * send.numel(), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return recv.cpu().numpy().reshape((world * r.shape[0],) + r.shape[1:])
 
 
 def slice_bounds(n, world, rank):
@@ -143,7 +180,11 @@ class ShardedRun:
     itself (rank 0 draws the unique id, torch.distributed only broadcasts its 128 bytes); under a "gloo" process group
     (test rig: several ranks on ONE GPU, which RCCL refuses) a host callback stands in for it."""
 
-    def __init__(self, sampler, group=None):
+    def __init__(self, sampler, group=None, allgather=None):
+        """``allgather``: optional host function ``f(block: float64[count]) -> float64[world * count]`` (rank order) that
+        replaces the collective -- the library then calls it once per half step through its callback communicator
+        (alabi_dist_comm_create_callback).  Default: RCCL under "nccl", ``dist.all_gather_into_tensor`` on host copies under
+        "gloo"."""
         self.s = sampler
         sampler._ensure_ens()
         self.group = group
@@ -154,7 +195,8 @@ class ShardedRun:
         comm = C.c_void_p()
         self._cb = None
         self.last_callback_error = None
-        if self.world > 1 and dist.get_backend(group) != "nccl":
+        self.last_chain_logp = None
+        if self.world > 1 and (allgather is not None or dist.get_backend(group) != "nccl"):
             hip = C.CDLL("libamdhip64.so")
             hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
             hip.hipStreamSynchronize.argtypes = [C.c_void_p]
@@ -166,9 +208,14 @@ class ShardedRun:
                     h = np.empty(count, dtype=np.float64)
                     if hip.hipMemcpy(h.ctypes.data_as(C.c_void_p), C.c_void_p(send), count * 8, 2) != 0:
                         return 1
-                    out = torch.empty(world * count, dtype=torch.float64)
-                    dist.all_gather_into_tensor(out, torch.from_numpy(h), group=group)
-                    o = out.numpy()
+                    if allgather is not None:
+                        o = np.ascontiguousarray(allgather(h), dtype=np.float64)
+                        if o.shape != (world * count,):
+                            raise ValueError("allgather must return world * count values")
+                    else:
+                        out = torch.empty(world * count, dtype=torch.float64)
+                        dist.all_gather_into_tensor(out, torch.from_numpy(h), group=group)
+                        o = out.numpy()
                     return 0 if hip.hipMemcpy(C.c_void_p(recv), o.ctypes.data_as(C.c_void_p), world * count * 8, 1) == 0 else 1
                 except Exception as ex:  # noqa: BLE001  (no exception may cross the C boundary: keep its text for the caller)
                     self.last_callback_error = repr(ex)
@@ -202,20 +249,46 @@ class ShardedRun:
             pass
         self._comm = None
 
-    def run(self, coords, nsteps, step0=0, a=2.0, thin_by=1, store=True):
-        """Returns (chain[nsteps//thin_by, W, d] or None, coords, logp, n_accept) -- identical on every rank."""
+    def stats(self):
+        """Counters of the C loop on this communicator: full chunks replayed from the captured hipGraph, chunks enqueued launch
+        by launch, graph captures, and whether the communicator is dead after a failed run."""
+        out = (C.c_longlong * 4)()
+        _lib.check(_lib.lib().alabi_dist_comm_stats(self._comm, out), "alabi_dist_comm_stats")
+        return dict(graph_replays=int(out[0]), eager_chunks=int(out[1]), graph_captures=int(out[2]), failed=bool(out[3]))
+
+    def run(self, coords, nsteps, step0=0, a=2.0, thin_by=1, store=True, logp0=None):
+        """Returns (chain[nsteps//thin_by, W, d] or None, coords, logp, n_accept) -- identical on every rank; the stored
+        log-probabilities are left in ``self.last_chain_logp``.
+
+        A failure on ONE rank (a HIP error, a collective that returns an error) would leave its peers inside an all-gather that
+        never completes, and returning to the caller would only move the hang to the next collective: with more than one rank
+        the error is logged and THIS PROCESS ENDS with exit status 70 (``os._exit``: no atexit handlers, no further
+        collectives) -- the launcher (torch.distributed.run) then takes the other ranks down."""
         dev = coords.device
         coords = coords.clone()
-        logp = self.s.compute_log_prob(coords).clone()
+        logp = (self.s.compute_log_prob(coords) if logp0 is None else logp0).clone()
         n_accept = torch.zeros(self.W, dtype=torch.int64, device=dev)
         nstore = nsteps // thin_by if store else 0
         chain = torch.empty((nstore, self.W, self.d), dtype=torch.float64, device=dev) if nstore else None
-        st = _lib.lib().alabi_ens_run_sharded(self.s._ens, self._comm, _lib.ptr(coords), _lib.ptr(logp), int(step0), int(nsteps),
-                                              int(thin_by), float(a), _lib.ptr(chain), None, _lib.ptr(n_accept),
-                                              _lib.current_stream())
-        if st != 0 and self.last_callback_error:
-            raise RuntimeError(f"alabi_ens_run_sharded: the all-gather callback failed: {self.last_callback_error}")
-        _lib.check(st, "alabi_ens_run_sharded")
+        chain_lp = torch.empty((nstore, self.W), dtype=torch.float64, device=dev) if nstore else None
+        # on the sampler's own stream: a chunk is captured into a hipGraph, which the null stream (torch's default) cannot do
+        run_stream = self.s._stream
+        run_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(run_stream):
+            st = _lib.lib().alabi_ens_run_sharded(self.s._ens, self._comm, _lib.ptr(coords), _lib.ptr(logp), int(step0), int(nsteps),
+                                                  int(thin_by), float(a), _lib.ptr(chain), _lib.ptr(chain_lp), _lib.ptr(n_accept),
+                                                  C.c_void_p(run_stream.cuda_stream))
+        if st == 0:
+            torch.cuda.current_stream().wait_stream(run_stream)
+        if st != 0:
+            detail = self.last_callback_error or _lib.lib().alabi_last_error().decode()
+            msg = f"alabi_ens_run_sharded failed on rank {self.rank} of {self.world} (status {st}): {detail}"
+            if self.world > 1:
+                import sys
+                print(msg + " -- peers may be inside the all-gather: ending this process (exit status 70)", file=sys.stderr, flush=True)
+                os._exit(70)
+            raise RuntimeError(msg)
+        self.last_chain_logp = chain_lp
         return chain, coords, logp, n_accept
 
 

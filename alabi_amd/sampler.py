@@ -39,7 +39,7 @@ class State:
 class EnsembleSampler:
     def __init__(self, nwalkers, ndim, gp, y, bounds, seed=None, a=2.0, pool=None, live_dangerously=False,
                  n_ensembles=1, logp_affine=(1.0, 0.0), normal_prior=None, logp_map=None, prior_fn=None, like_fn=None,
-                 gate_box=True, **unused):
+                 gate_box=True, shard=False, group=None, **unused):
         """``n_ensembles`` > 1 runs that many INDEPENDENT ensembles of ``nwalkers`` walkers in the same kernel
         launches (rows [e*nwalkers, (e+1)*nwalkers) of every array belong to ensemble e).
         ``logp_affine=(scale, shift)``: log-probability = scale * GP mean + shift inside the box (an affine y scaler).
@@ -52,7 +52,12 @@ class EnsembleSampler:
         With either one set, every half step is split into a propose launch, the host call and an accept launch
         (alabi_ens_propose / alabi_ens_accept): the ensemble, the draws and the accept test stay on the device.  With
         ``like_fn=None`` the surrogate part is evaluated by the propose kernel; ``gate_box`` says whether that value is
-        -inf outside ``bounds`` (True when the prior is the box itself, False when ``prior_fn`` is the whole prior)."""
+        -inf outside ``bounds`` (True when the prior is the box itself, False when ``prior_fn`` is the whole prior).
+        ``shard=True`` under an initialised ``torch.distributed`` group of more than one rank (``group``: default WORLD): ONE
+        ensemble whose active half is partitioned over the ranks, an all-gather of the new rows per half step
+        (alabi_amd.dist.ShardedRun -> alabi_ens_run_sharded); every rank must construct the sampler with the same arguments and
+        make the same calls, and every rank ends with the same chain (counter-based draws).  The reference's analogue:
+        ``EnsembleSampler(..., pool=pool)`` spreading one ensemble's lnprob calls over processes (alabi/core.py:2300, :2322)."""
         if not isinstance(gp, HipGP):
             raise TypeError("EnsembleSampler needs the HipGP surrogate (the log-probability is fused into the kernel)")
         self.nwalkers = int(nwalkers)
@@ -83,6 +88,9 @@ class EnsembleSampler:
         self.gate_box = bool(gate_box)
         if self.generic and self.n_ensembles != 1:
             raise ValueError("host callables need n_ensembles == 1")
+        self.shard, self.group, self._sharded, self._sharded_ens = bool(shard), group, None, None
+        if self.shard and (self.generic or self.n_ensembles != 1):
+            raise ValueError("shard=True needs the fused log-probability (no host callables) and n_ensembles == 1")
         if seed is None:
             seed = int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).view(np.uint64)[0])
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -146,6 +154,9 @@ class EnsembleSampler:
         st["_ens"] = None
         st["_ens_gp_handle"] = None
         st["_stream"] = None
+        st["_sharded"] = None
+        st["_sharded_ens"] = None
+        st["group"] = None
         st["prior_fn_host"] = None      # host callables (often closures) are not part of the saved state
         st["like_fn_host"] = None
         for k in ("_coords", "_logp", "_naccept"):
@@ -271,6 +282,25 @@ class EnsembleSampler:
             if torch.isnan(self._logp).any():
                 raise ValueError("The initial log_prob was NaN")
         self._ensure_ens()
+        if self.shard:
+            from .dist import ShardedRun, world_info
+            if world_info(self.group)[1] > 1:
+                t0s = time.perf_counter()
+                nstore = nsteps // thin_by if store else 0
+                if self._sharded is None or self._sharded.s is not self or self._sharded_ens is not self._ens:
+                    self._sharded, self._sharded_ens = ShardedRun(self, self.group), self._ens
+                ch, co, lp, nacc = self._sharded.run(self._coords, nsteps, step0=self._rng_step, a=self.a, thin_by=thin_by,
+                                                     store=bool(nstore), logp0=self._logp)
+                torch.cuda.current_stream().synchronize()
+                self._coords, self._logp = co, lp
+                self._naccept += nacc
+                self.last_path = "sharded"
+                self.last_run_seconds = time.perf_counter() - t0s
+                self.iteration += nsteps
+                self._rng_step += nsteps
+                if nstore:
+                    self._chains.append(ch); self._chain_lps.append(self._sharded.last_chain_logp); self._thins.append(thin_by)
+                return State(self._coords.cpu().numpy(), self._logp.cpu().numpy())
         nstore = nsteps // thin_by if store else 0
         dev = self._coords.device
         chain = torch.empty((nstore, self.total_walkers, self.ndim), dtype=torch.float64, device=dev) if nstore else None

@@ -259,6 +259,10 @@ int alabi_dist_unique_id(void* id_out /* host, 128 bytes */);
 int alabi_dist_comm_create(const void* id /* host, 128 bytes */, int rank, int nranks, alabi_comm** out);
 int alabi_dist_comm_create_callback(alabi_allgather_fn fn, void* user, int rank, int nranks, alabi_comm** out);
 int alabi_dist_comm_destroy(alabi_comm* comm);
+/* Counters of alabi_ens_run_sharded on this communicator (host int64[4]): [0] full chunks replayed from the captured hipGraph,
+ * [1] chunks enqueued launch by launch, [2] graph captures, [3] 1 once a run failed on this rank with peers possibly inside the
+ * collective (the communicator is then dead: every later run returns ALABI_HIP_ERROR; end the process). */
+int alabi_dist_comm_stats(alabi_comm* comm, long long* out /* host [4] */);
 int alabi_ens_run_sharded(alabi_ens* ens, alabi_comm* comm, double* coords, double* logp, long long step0,
                           long long nsteps, int thin_by, double a, double* chain, double* chain_logp,
                           long long* n_accept, void* stream);

@@ -153,3 +153,49 @@ def test_sharded_candidate_scan_matches_single_process(world, M):
         assert i == ref_i and (i < 0 or v == u[ref_i]), (r, v, i, ref_i)
         cover.append((b, e))
     assert cover[0][0] == 0 and cover[-1][1] == M and all(cover[k][1] == cover[k + 1][0] for k in range(world - 1))
+
+
+def _helpers_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from alabi_amd import dist as adist
+    assert adist.world_info() == (rank, world)
+    # the CV search over several ranks: every rank scores candidates rank, rank + world, ... (+inf elsewhere), one MIN all-reduce
+    full = np.array([3.0, np.inf, 1.5, 2.5, 0.25, np.inf, 7.0])
+    mine = np.where(np.arange(len(full)) % world == rank, full, np.inf)
+    red = adist.allreduce_array(mine, "min")
+    tot = adist.allreduce_array([float(rank), 1.0], "sum")
+    # the best `ntop` candidates of every slice, gathered in rank order
+    rows = np.array([[10.0 * rank + k, rank * 100 + k] for k in range(3)])
+    allrows = adist.allgather_rows(rows)
+    # replica samples of different lengths
+    samples = adist.gather_replicas(np.full((2 + rank, 2), float(rank)))
+    out[rank] = (red, tot, allrows, samples)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_collective_helpers_of_the_surrogate_model_paths(world):
+    """alabi_amd.dist.allreduce_array / allgather_rows / gather_replicas: what SurrogateModel.init_gp(cv), find_next_point and
+    run_emcee exchange between ranks (score vectors, top candidates, replica samples) -- identical on every rank."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_helpers_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    full = np.array([3.0, np.inf, 1.5, 2.5, 0.25, np.inf, 7.0])
+    for r in range(world):
+        red, tot, allrows, samples = out[r]
+        np.testing.assert_array_equal(red, full)
+        np.testing.assert_array_equal(tot, [sum(range(world)), world])
+        want = np.array([[10.0 * q + k, q * 100 + k] for q in range(world) for k in range(3)])
+        np.testing.assert_array_equal(allrows, want)
+        np.testing.assert_array_equal(samples, np.vstack([np.full((2 + q, 2), float(q)) for q in range(world)]))
+
+
+def test_world_info_without_a_process_group():
+    from alabi_amd import dist as adist
+    assert adist.world_info() == (0, 1)
+    np.testing.assert_array_equal(adist.allreduce_array([1.0, 2.0], "min"), [1.0, 2.0])
+    np.testing.assert_array_equal(adist.allgather_rows(np.ones((2, 3))), np.ones((2, 3)))

@@ -98,10 +98,23 @@ def test_sharded_run_single_rank_and_rccl_loads(monkeypatch):
     # two full chunks (1024 steps each: the captured graph is replayed) plus a remainder, thinned chain, RCCL communicator
     ref3 = EnsembleSampler(W, 4, gp, y, bounds, seed=5); ref3.run_mcmc(p0, 2100, thin_by=7)
     s3 = EnsembleSampler(W, 4, gp, y, bounds, seed=5)
-    chain3, coords3, logp3, nacc3 = run2.__class__(s3).run(torch.as_tensor(p0, device="cuda"), 2100, thin_by=7)
+    run3 = ShardedRun(s3)
+    chain3, coords3, logp3, nacc3 = run3.run(torch.as_tensor(p0, device="cuda"), 2100, thin_by=7)
     assert np.array_equal(chain3.cpu().numpy(), ref3.get_chain())
     assert np.array_equal(nacc3.cpu().numpy(), ref3._naccept.cpu().numpy())
     assert np.array_equal(coords3.cpu().numpy(), ref3.get_last_sample().coords)
+    st = run3.stats()
+    assert st["graph_replays"] == 2 and st["eager_chunks"] == 1 and st["graph_captures"] == 1 and not st["failed"], st
+    # the captured launches carry the handle's settings: a changed setting must re-capture, not replay stale arguments
+    s4 = EnsembleSampler(W, 4, gp, y, bounds, seed=5, logp_affine=(2.0, -1.0))
+    ref4 = EnsembleSampler(W, 4, gp, y, bounds, seed=5, logp_affine=(2.0, -1.0)); ref4.run_mcmc(p0, 1100)
+    chain4, _, _, _ = ShardedRun(s4).run(torch.as_tensor(p0, device="cuda"), 1100)
+    assert np.array_equal(chain4.cpu().numpy(), ref4.get_chain())
+    monkeypatch.setenv("ALABI_ENS_GRAPH", "0")              # and without the graph: the same chain, every chunk enqueued eagerly
+    run5 = ShardedRun(EnsembleSampler(W, 4, gp, y, bounds, seed=5))
+    chain5, _, _, _ = run5.run(torch.as_tensor(p0, device="cuda"), 2100, thin_by=7)
+    assert np.array_equal(chain5.cpu().numpy(), ref3.get_chain()) and run5.stats()["graph_replays"] == 0
+    monkeypatch.delenv("ALABI_ENS_GRAPH")
     del run2
     buf = C.create_string_buffer(128)
     _lib.check(_lib.lib().alabi_dist_unique_id(buf), "alabi_dist_unique_id")

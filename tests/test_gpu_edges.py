@@ -1,6 +1,7 @@
 """Edge cases of the C ABI and the host mirror on the GPU: tiny / ragged / maximal sizes, empty batches,
 bad arguments, NaN inputs, candidates that all fail."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -129,3 +130,36 @@ def test_sampler_small_ensembles_and_thinning():
     s = EnsembleSampler(8, 2, g, y, bounds, seed=2)
     st = s.run_mcmc(p0, 200)
     assert np.all(np.isfinite(st.log_prob)) and np.all(np.abs(st.coords) < 3.0)
+
+
+def test_ensemble_with_zero_alpha_points_and_short_length_scales():
+    """A training set whose targets equal the mean (alpha identically 0) and inputs many length scales from their centre: the
+    squared-exponential half-step kernels (se_pair_terms: exp(q.x - |q|^2/2 - h)) must return exactly the mean inside the box --
+    a point without weight contributes nothing, wherever it lies (round-3 advisor: with its real coordinates the padded exponent
+    could overflow)."""
+    from alabi_amd import EnsembleSampler, HipGP
+    rng = np.random.RandomState(0)
+    d, N, W = 3, 300, 16
+    X = rng.uniform(-40.0, 40.0, (N, d))                     # ~ +-90 length scales
+    y = np.full(N, 1.25)
+    g = HipGP(d, 1.25, -8.0, 0.0, np.log(np.full(d, 0.2)))
+    g.compute(X)
+    bounds = np.array([[-40.0, 40.0]] * d)
+    p0 = rng.uniform(-35, 35, (W, d))
+    for stream in ("1", "0"):
+        os.environ["ALABI_ENS_STREAM"] = stream
+        try:
+            s = EnsembleSampler(W, d, g, y, bounds, seed=3)
+            s.run_mcmc(p0, 40)
+        finally:
+            os.environ.pop("ALABI_ENS_STREAM", None)
+        lp = s.get_log_prob()
+        assert np.all(np.isfinite(lp)) and np.all(lp == 1.25), (stream, lp.min(), lp.max())
+        assert s.acceptance_fraction.mean() > 0.2
+    # half the targets off the mean: the live half decides, against the oracle
+    from oracle.gp_oracle import OracleGP
+    y2 = y.copy(); y2[::2] += rng.normal(0, 0.3, len(y2[::2]))
+    o = OracleGP(d, 1.25, -8.0, 0.0, np.log(np.full(d, 0.2))).compute(X)
+    s = EnsembleSampler(W, d, g, y2, bounds, seed=3)
+    q = np.vstack([X[:W // 2] + 0.05, p0[:W // 2]])
+    np.testing.assert_allclose(s.compute_log_prob(q).cpu().numpy(), o.predict(y2, q), rtol=1e-9, atol=1e-12)
