@@ -141,18 +141,149 @@ def cpu_baseline(cfg, budget_s=10.0, cores=1):
                       ", single-point mean-only predict with cached factorisation"}
 
 
+def pmc_file():
+    """The committed PMC passes of this bench command (tools/collect_profiles.sh): the newest round's file."""
+    for name in ("r04_pmc_by_kernel.json", "r03_pmc_by_kernel.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            return path
+    return None
+
+
+def cpu_end_to_end_baseline(cfg, budget_s=12.0):
+    """Reference-shaped CPU legs of the end-to-end calls (bounded samples, extrapolated where stated), on the oracle:
+    * one active-learning iteration = find_next_point as the reference runs it -- `nopt` = 5 scipy L-BFGS-B starts on the BAPE
+      utility, one single-point predict(return_var=True) per objective call (alabi/core.py:1587-1667, utility.py:1030-1163;
+      gradients by scipy's finite differences, i.e. use_grad_opt=False: the reference's own gradient route inverts K per call)
+      -- plus the from-scratch refit of the N + 1 points (core.py:1780 -> :1158);
+    * one fold fit of the k-fold CV search (gp_utils.py:568-600: compute on 0.8 N rows, log-likelihood, predict the held-out
+      rows), extrapolated to the 875 fits of init_gp(hyperopt_method="cv") with the default 100 + 50 + 25 candidates x 5 folds."""
+    from scipy.optimize import minimize
+    from oracle.gp_oracle import OracleGP
+    from oracle.utility_oracle import bape_utility
+    h, d, X, y, b = cfg["hyper"], cfg["d"], cfg["X"], cfg["y"], cfg["bounds"]
+    out = {"kind": "port", "cores": "numpy / scipy default threads"}
+    best = None
+    for _ in range(2):                                                  # (the first call also warms the BLAS threads up)
+        t0 = time.perf_counter()
+        gp = OracleGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X)
+        gp._compute_alpha(y)
+        dt0 = 1e3 * (time.perf_counter() - t0)
+        best = dt0 if best is None else min(best, dt0)
+    out["refit_from_scratch_ms"] = best
+    predict = lambda t: gp.predict(y, np.atleast_2d(t), return_var=True)  # noqa: E731
+    obj = lambda t: float(bape_utility(t, predict, b))  # noqa: E731
+    rs = np.random.RandomState(3)
+    t0 = time.perf_counter(); nstart = 0; ncall = [0]
+
+    def counted(t):
+        ncall[0] += 1
+        return obj(t)
+    while nstart < 5 and time.perf_counter() - t0 < budget_s:
+        x0 = b[:, 0] + (b[:, 1] - b[:, 0]) * rs.rand(d)
+        minimize(counted, x0, method="L-BFGS-B", bounds=[tuple(r) for r in b], options={"maxiter": 15})
+        nstart += 1
+    dt = time.perf_counter() - t0
+    out["find_next_point_ms"] = 1e3 * dt * 5.0 / max(nstart, 1)
+    out["active_train_iter_ms"] = out["find_next_point_ms"] + out["refit_from_scratch_ms"]
+    out["sample_active"] = (f"{nstart} of 5 L-BFGS-B starts (maxiter 15, {ncall[0]} single-point predict(return_var) calls, "
+                            f"{dt:.1f} s) scaled to 5, + one from-scratch refit at N = {len(X)}")
+    n = len(X)
+    perm = np.random.RandomState(4).permutation(n)
+    val, train = np.sort(perm[: n // 5]), np.sort(perm[n // 5:])
+    t0 = time.perf_counter(); nfit = 0
+    while nfit < 3 or (time.perf_counter() - t0 < 3.0 and nfit < 40):
+        g = OracleGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]).compute(X[train])
+        g.log_likelihood(y[train]); g.predict(y[train], X[val])
+        nfit += 1
+    per_fit = (time.perf_counter() - t0) / nfit
+    out["cv_fold_fit_ms"] = 1e3 * per_fit
+    out["init_gp_cv_s_extrapolated"] = 875 * per_fit
+    out["sample_cv"] = f"{nfit} fold fits (compute on {len(train)} rows + log-likelihood + predict {len(val)} rows), x 875 / {nfit}"
+    return out
+
+
+def end_to_end_extras(cfg):
+    """What a user of SurrogateModel waits for besides the sampler (reference: 6.29 it/s active_train in
+    docs/source/gp_tutorial.ipynb:202, on a smaller problem): init_gp with the default k-fold CV search (100 + 50 + 25 candidates
+    x 5 folds = 875 fits of 0.8 N rows) and with the ML fit, one re-optimisation of the hyper-parameters as active_train runs it
+    every gp_opt_freq iterations, and an active-learning iteration (scan + zoom + polish, true-function call, append) at C3 and
+    with 10^6 candidates at the C5 size.  Wall-clock with a device synchronisation on both sides."""
+    import tempfile
+    import torch
+    from alabi_amd import SurrogateModel
+    from alabi_amd.workloads import make_config
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="alabi_bench_")
+
+    def model(c, seed=0):
+        f = os.path.join(tmp, f"{c['name']}_train.npz")
+        if not os.path.exists(f):
+            np.savez(f, theta=c["X"], y=c["y"].reshape(-1, 1))
+        sm = SurrogateModel(lnlike_fn=c["fn"], bounds=c["bounds"], savedir=tmp, verbose=False, random_state=seed, cache=False)
+        sm.init_samples(train_file=f)
+        return sm
+
+    def timed(fn):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, r
+    try:
+        for method, key in (("cv", "init_gp_cv_s"), ("ml", "init_gp_ml_s")):
+            times = []
+            for rep in range(3):
+                sm = model(cfg, seed=rep)
+                times.append(timed(lambda: sm.init_gp(hyperopt_method=method))[0])
+            res[key] = min(times[1:])
+            res[key + "_first_call"] = times[0]
+        res["init_gp_cv_fits"] = 875
+        res["init_gp_cv_tflops"] = 875 * (0.8 * cfg["N"]) ** 3 / 3.0 / res["init_gp_cv_s"] / 1e12
+        # sm now holds the ML-fitted GP: one hyper-parameter re-optimisation each way, then plain iterations
+        sm.opt_gp_kwargs["hyperopt_method"] = "cv"
+        res["opt_gp_cv_ms"] = 1e3 * min(timed(lambda: sm._opt_gp(**sm.opt_gp_kwargs))[0] for _ in range(2))
+        sm.opt_gp_kwargs["hyperopt_method"] = "ml"
+        res["opt_gp_ml_ms"] = 1e3 * min(timed(lambda: sm._opt_gp(**sm.opt_gp_kwargs))[0] for _ in range(2))
+        sm.active_train(niter=2, gp_opt_freq=10 ** 6)                                   # warm-up (L^-1 cache, first append)
+        niter = 12
+        dt, _ = timed(lambda: sm.active_train(niter=niter, gp_opt_freq=10 ** 6))
+        res["active_train_iter_ms"] = 1e3 * dt / niter
+        res["active_train_iter_detail"] = "C3 + 14 points: scan 16384 candidates + 4 zoom stages + polish, lnlike call, append; no hyper-fit"
+        res["active_train_appended"] = int(getattr(sm.gp, "appended", 0))
+        del sm
+        torch.cuda.empty_cache()
+    except Exception as ex:  # noqa: BLE001
+        res["error_C3"] = repr(ex)[:300]
+    try:
+        c5 = make_config("C5")
+        sm = model(c5, seed=5)
+        sm.init_gp(hyperopt_method="ml", gp_nopt=1, optimizer_kwargs={"maxiter": 1})
+        h = c5["hyper"]
+        sm.gp.set_parameter_vector(np.concatenate([[h["mean"], h["log_white_noise"], h["log_amp"]], h["log_M"]]))
+        sm.gp.compute(sm._theta, quiet=True)
+        kw = {"ncand": 1_000_000, "refine": 1, "nrefine": 4096, "polish": 5}
+        sm.active_train(niter=1, gp_opt_freq=10 ** 6, optimizer_kwargs=kw)              # warm-up: builds L^-1 (N = 10000)
+        dt, _ = timed(lambda: sm.active_train(niter=2, gp_opt_freq=10 ** 6, optimizer_kwargs=kw))
+        res["active_train_iter_ms_C5_1e6_candidates"] = 1e3 * dt / 2
+        del sm
+        torch.cuda.empty_cache()
+    except Exception as ex:  # noqa: BLE001
+        res["error_C5"] = repr(ex)[:300]
+    return res
+
+
 def pmc_summary(prefix, which="max"):
     """Counters of the kernel whose name starts with `prefix` from the committed PMC passes of this round
-    (profiles/r03_pmc_by_kernel.json: rocprofv3 --pmc runs of this same bench command, tools/collect_profiles.sh).
+    (profiles/rNN_pmc_by_kernel.json: rocprofv3 --pmc runs of this same bench command, tools/collect_profiles.sh).
     FETCH_SIZE is doubled (16-byte-per-lane streaming reads are tallied at half their bytes on gfx950,
     MI355X_MICROARCH.md section HBM) unless the kernel's fetches are 8-byte polls.  None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_by_kernel.json")
-    if not os.path.exists(path):
+    path = pmc_file()
+    if path is None:
         return None
     try:
         allk = json.load(open(path))
         v = next(v for k, v in allk.items() if k.replace("void ", "").startswith("alabi::" + prefix))
-        out = {"source": "profiles/r03_pmc_by_kernel.json", "statistic": which + " over the launches of the profiled run"}
+        out = {"source": os.path.relpath(path, ROOT), "statistic": which + " over the launches of the profiled run"}
         for c, key in (("FETCH_SIZE", "fetch_KB"), ("WRITE_SIZE", "write_KB"), ("SQ_INSTS_VALU_MFMA_F64", "mfma_f64_instructions"),
                        ("SQ_VALU_MFMA_BUSY_CYCLES", "mfma_busy_cycles_summed_over_simds"), ("SQ_VALU_MFMA_COEXEC_CYCLES", "valu_mfma_coexec_cycles"),
                        ("SQ_INSTS_VALU", "valu_instructions"), ("SQ_WAVE_CYCLES", "wave_quad_cycles"), ("SQ_WAIT_ANY", "wait_any_quad_cycles"),
@@ -313,7 +444,7 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     # CPU baselines first: the multi-core one forks a pool, which must happen before the GPU is initialised
-    cpu_base = cpu_base_all = cpu_base_vec = cpu_pred = None
+    cpu_base = cpu_base_all = cpu_base_vec = cpu_pred = cpu_e2e = None
     cpu_chain = None
     if world == 1 and not args.no_cpu_baseline:
         cfg0 = make_config(args.config, N=args.ntrain, W=args.walkers)
@@ -321,6 +452,10 @@ def main():
         cpu_chain = []
         cpu_base_vec = cpu_baseline_vectorized(cfg0, budget_s=12.0, keep_chain=cpu_chain)
         cpu_pred = cpu_predict_baseline(cfg0)
+        try:
+            cpu_e2e = cpu_end_to_end_baseline(cfg0)
+        except Exception as ex:  # noqa: BLE001
+            cpu_e2e = {"error": repr(ex)[:200]}
         ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         ncores = max(1, min(ncores, 64))
         if ncores > 1:
@@ -480,8 +615,8 @@ def main():
         # MI355X_MICROARCH.md section HBM).  A PMC pass cannot run inside this process, so the number is read from
         # profiles/ and is null when the file is absent or the workload differs from the profiled one.
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_by_kernel.json")
-        if os.path.exists(pmc_path) and args.config == "C3" and args.ensembles == 1 and not shard:
+        pmc_path = pmc_file()
+        if pmc_path is not None and args.config == "C3" and args.ensembles == 1 and not shard:
             try:
                 allk = json.load(open(pmc_path))
                 pmc = next(v for k, v in allk.items() if k.startswith("void alabi::" + kernel_name.split("<")[0] + "<"))
@@ -550,6 +685,11 @@ def main():
                 t_cfg = time.perf_counter()
                 extras["configs"] = config_extras()
                 extras["configs_wall_s"] = time.perf_counter() - t_cfg
+                t_cfg = time.perf_counter()
+                extras["end_to_end"] = end_to_end_extras(cfg)
+                extras["end_to_end"]["wall_s"] = time.perf_counter() - t_cfg
+                if cpu_e2e is not None:
+                    extras["end_to_end"]["cpu_baseline"] = cpu_e2e
             out["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             out["parity_gate"] = parity_gate(cfg, gp, y_dev, cpu_chain, args)
