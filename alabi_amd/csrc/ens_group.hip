@@ -565,6 +565,11 @@ ens_group_kernel(GroupArgs p) {
         GRP_STAMP(c3);
         grp_barrier();                                       // barrier B: the wave partials are in LDS
         // ---- phase 3 (wave 0): this member's partial sums, published like rows; the other waves go on ----
+        // (Round 4, measured and not kept -- tools/experiments/ens_group_publisher_last_arriver.patch: the wave that finishes its sums
+        // LAST, found with an arrival counter in LDS, publishing in front of barrier B instead of wave 0 behind it: C4 4.85 -> 5.04 us
+        // per half step, C5 size 17.87 -> 18.05, with the poll delay re-tuned 4.96.  The last arriver is one of the waves w + 4, which at
+        // C4 are the waves that run the rows phase: the publish then sits in front of their own set-up and first look, while wave 0
+        // has nothing else to do there.)
         if (wv == 0) {
             unsigned long long* part_h = p.part + (((size_t)hh * E + e) * NG + g) * (size_t)QPAD * G + m;
             for (int pp = lane; pp < cnt; pp += 64) {

@@ -30,6 +30,7 @@ def _jobs(n, d, seed, sizes, nval=37):
 @pytest.mark.parametrize("n,d,sizes", [
     (1800, 6, [1600, 1601, 1536, 1100, 1700, 1664, 1280, 1599, 1600, 1345, 1024]),   # 16..27 block columns: the single path is the queue too
     (700, 3, [64, 100, 130, 257, 600, 1, 320, 65]),                               # 1..10 block columns (single path: launch per step)
+    (5300, 5, [5000, 4100, 3333]),                                                # 53..79 block columns: long groups, many 2 x 2 tasks
 ])
 def test_batch_factors_bit_identical_and_results_match_single_path(n, d, sizes, monkeypatch):
     import torch
