@@ -44,6 +44,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 #define ALABI_GRP_EMPTY 0x7FF8A1AB1D15EA5Eull   // the sentinel of the version history (ensemble.hip: ALABI_HIST_EMPTY)
 #define ALABI_GRP_NW 8                           // waves per workgroup (512 threads, two per SIMD)
+// (Round 4, measured and not kept -- tools/experiments/ens_group_exp_table_2048.patch: a 2048-entry exp table (16 KB of LDS) with a
+// degree-3 polynomial, one fused multiply-add fewer per kernel evaluation (9 instead of 10 fp64 instructions, 1.93 ulp): C4 4.85 vs
+// 4.86 us per half step, C5 size 17.85 vs 17.97 -- the kernel sums are not bound by the count of vector instructions.)
 
 struct GroupArgs {
     unsigned long long* hist;            // [(K+1)][E*W][d+2] version history: row 0 = state before the launch, rows 1..K written here
