@@ -12,7 +12,7 @@
 //                          one list and head counter per XCD, chains of different matrices side by side)
 //   batch_solve_kernel     alpha = K^-1 (y - m), log-determinant, (y - m)^T alpha            (one workgroup per job)
 //   batch_predict_kernel   mean at the validation rows                                       (32 queries per workgroup)
-// followed by ONE read-back.  Jobs are processed in chunks that fit the workspace (ALABI_BATCH_BYTES, default 6 GiB).
+// followed by ONE read-back.  Jobs are processed in chunks that fit the workspace (ALABI_BATCH_BYTES, default 16 GiB).
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -260,7 +260,11 @@ int alabi_gp_batch_create(int d, int kernel_type, long long workspace_bytes, ala
     alabi_gp_batch* b = new (std::nothrow) alabi_gp_batch();
     if (!b) return ALABI_BAD_ARGUMENT;
     b->d = d; b->kernel_type = kernel_type;
-    size_t budget = (size_t)6 << 30;
+    // matrices in flight per launch: 16 GiB hold every fold of a C3-sized search stage (500 x 20 MB) and 32 matrices of N = 8000
+    // (measured at N = 8000: 12 per launch 5.7 ms per fit, 32 per launch 4.6 ms); never more than half of what is free
+    size_t budget = (size_t)16 << 30;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 < budget) budget = free_b / 2;
     if (const char* e = getenv("ALABI_BATCH_BYTES")) { const long long v = atoll(e); if (v > 0) budget = (size_t)v; }
     if (workspace_bytes > 0) budget = (size_t)workspace_bytes;
     b->budget = budget;
@@ -411,13 +415,22 @@ int alabi_gp_batch_fit_predict(alabi_gp_batch* b, const double* X, const double*
             if (!std::isfinite(hyper[(size_t)job * hs + k])) return ALABI_BAD_ARGUMENT;
     }
     hipStream_t s = bstream(stream);
+    // chunks of about equal size (48 jobs with room for 32: 24 + 24, not 32 + 16: every launch ends with a tail in which the last
+    // matrices' chains run alone)
+    size_t total = 0;
+    for (int job = 0; job < njobs; ++job) {
+        const size_t Npad = (size_t)round_up((int)(train_off[job + 1] - train_off[job]), ALABI_BLK);
+        total += Npad * Npad * sizeof(double);
+    }
+    const size_t nchunks = (total + b->budget - 1) / b->budget;
+    const size_t target = nchunks > 0 ? (total + nchunks - 1) / nchunks : total;
     int c0 = 0;
     while (c0 < njobs) {
         size_t bytes = 0;
         int c1 = c0;
         while (c1 < njobs && c1 - c0 < 8192) {
             const size_t Npad = (size_t)round_up((int)(train_off[c1 + 1] - train_off[c1]), ALABI_BLK);
-            if (c1 > c0 && bytes + Npad * Npad * sizeof(double) > b->budget) break;
+            if (c1 > c0 && (bytes + Npad * Npad * sizeof(double) > b->budget || bytes >= target)) break;
             bytes += Npad * Npad * sizeof(double);
             ++c1;
         }

@@ -77,7 +77,7 @@ int alabi_gp_last_pivot(alabi_gp* gp, int* pivot /* host, 1-based like LAPACK in
  *   val_idx    the same for the validation rows (may be empty); mu_val [val_off[njobs]] receives the held-out means
  *   nll        host [njobs]: -log-likelihood of the training rows (+inf where K is not positive definite)
  *   status     host [njobs]: 0, or LAPACK's 1-based pivot index where the factorisation broke down (mu_val is then NaN)
- * Jobs are processed in chunks whose matrices fit `workspace_bytes` (0: ALABI_BATCH_BYTES or 6 GiB).  Factors are bit-identical
+ * Jobs are processed in chunks whose matrices fit `workspace_bytes` (0: ALABI_BATCH_BYTES or 16 GiB, at most half of the free memory).  Factors are bit-identical
  * to alabi_gp_compute on the same rows.  Synchronises with `stream`.  N <= 12288 per job. */
 typedef struct alabi_gp_batch alabi_gp_batch;
 int alabi_gp_batch_create(int d, int kernel_type, long long workspace_bytes, alabi_gp_batch** out);

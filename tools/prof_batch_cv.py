@@ -1,6 +1,6 @@
 """Batched fit (alabi_gp_batch_fit_predict) at the shape of init_gp(hyperopt_method="cv") on C3: B jobs of 0.8 N = 1600 rows, d = 10.
 Prints ms per call, fits/s and the aggregate factorisation rate (N^3/3 flops per job) for a sweep of the queue's knobs, then
-init_gp(cv) / init_gp(ml) end to end.  usage: python tools/prof_batch_cv.py [B] [sweep]"""
+init_gp(cv) / init_gp(ml) end to end.  usage: python tools/prof_batch_cv.py [B] [sweep|-] [config]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,7 +10,8 @@ from alabi_amd.workloads import make_config
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 sweep = len(sys.argv) > 2 and sys.argv[2] == "sweep"
-cfg = make_config("C3")
+cfg_name = sys.argv[3] if len(sys.argv) > 3 else "C3"
+cfg = make_config(cfg_name)
 X, y, h, d = cfg["X"], cfg["y"], cfg["hyper"], cfg["d"]
 n = len(X)
 rng = np.random.RandomState(0)
@@ -46,11 +47,16 @@ def run(tag, reps=3):
     return ll, mu
 
 
-settings = [(8, 8, None, None, None)]
+settings = [None]                                   # None: whatever the environment says (the library's defaults)
 if sweep:
     settings = [(8, w, gk, None, "1") for gk in (6, 8, 10, 12) for w in (0, 6, 8, 12, 16)]
 ref = None
-for lists, window, gk, near, u4 in settings:
+for setting in settings:
+    if setting is None:
+        ll, mu = run("environment / defaults")
+        ref = (ll.copy(), mu.clone())
+        continue
+    lists, window, gk, near, u4 = setting
     os.environ["ALABI_BATCH_LISTS"], os.environ["ALABI_BATCH_WINDOW"] = str(lists), str(window)
     os.environ["ALABI_BATCH_LEFT"] = "0" if gk == "left0" else "1"
     for k, v in (("ALABI_BATCH_GK", gk), ("ALABI_CHOL_NEAR", near), ("ALABI_CHOL_UPDATE4", u4)):
@@ -63,9 +69,10 @@ for lists, window, gk, near, u4 in settings:
         ref = (ll.copy(), mu.clone())
     else:
         assert np.array_equal(ll, ref[0]) and torch.equal(mu, ref[1]), "results depend on the queue order"
-for k in ("ALABI_BATCH_LISTS", "ALABI_BATCH_WINDOW", "ALABI_BATCH_GK", "ALABI_BATCH_LEFT", "ALABI_CHOL_NEAR", "ALABI_CHOL_UPDATE4"):
-    os.environ.pop(k, None)
 if sweep:
+    for k in ("ALABI_BATCH_LISTS", "ALABI_BATCH_WINDOW", "ALABI_BATCH_GK", "ALABI_BATCH_LEFT", "ALABI_CHOL_NEAR", "ALABI_CHOL_UPDATE4"):
+        os.environ.pop(k, None)
+if sweep or cfg_name != "C3":
     sys.exit(0)
 os.environ["ALABI_BATCH_QUEUE"] = "0"
 if B <= 100:
