@@ -51,6 +51,7 @@ SIGNATURES = {
     "alabi_gp_batch_get_factor": (_i, [_vp, _i, _vp, _vp]),
     "alabi_gp_batch_get_alpha": (_i, [_vp, _i, _vp, _vp]),
     "alabi_gp_batch_timeouts": (_i, [_vp, _pi]),
+    "alabi_cv_fold_lists": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "alabi_gp_set_mean": (_i, [_vp, _d]),
     "alabi_gp_get_alpha": (_i, [_vp, _vp, _vp]),
     "alabi_gp_get_factor": (_i, [_vp, _vp, _vp]),

@@ -36,13 +36,22 @@ struct BatchJob {
     double inv_len[ALABI_MAX_DIM];
 };
 
+// A row index outside [0, n_rows) must never reach an address: it reads as an all-zero row / a zero target and raises *bad, which
+// the host turns into ALABI_BAD_ARGUMENT after the call (the row lists come from the caller; alabi_cv_fold_lists builds valid ones).
+__device__ inline int batch_row(const int* __restrict__ idx, int i, int n_rows, int* __restrict__ bad) {
+    const int r = idx[i];
+    if ((unsigned)r < (unsigned)n_rows) return r;
+    *bad = 1;
+    return -1;
+}
+
 __global__ void __launch_bounds__(256)
-batch_prepare_kernel(const BatchJob* __restrict__ jobs, const double* __restrict__ X, int d, int dbucket) {
+batch_prepare_kernel(const BatchJob* __restrict__ jobs, const double* __restrict__ X, int d, int dbucket, int n_rows, int* __restrict__ bad) {
     const BatchJob& j = jobs[blockIdx.y];
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n == 0) *j.info = 0;
     if (n >= j.Npad) return;
-    const int src = n < j.N ? j.train[n] : -1;
+    const int src = n < j.N ? batch_row(j.train, n, n_rows, bad) : -1;
     for (int k = 0; k < dbucket; ++k) {
         double v = 0.0;
         if (src >= 0 && k < d) v = X[(size_t)src * d + k] * j.inv_len[k];
@@ -71,7 +80,7 @@ batch_assemble_kernel(const BatchJob* __restrict__ jobs, int d, int kernel_type)
 // again (coalesced), four partial sums per column, the transposed substitution.  2 N^2 flops reading the lower triangle twice:
 // bound by what one CU can pull (~0.3 ms at N = 1600), which 256 jobs at a time hide.
 __global__ void __launch_bounds__(256)
-batch_solve_kernel(const BatchJob* __restrict__ jobs, const double* __restrict__ y) {
+batch_solve_kernel(const BatchJob* __restrict__ jobs, const double* __restrict__ y, int n_rows, int* __restrict__ bad) {
     extern __shared__ double bs_z[];                     // [Npad]
     __shared__ double lkk[64][65];
     __shared__ double rhs[64];
@@ -85,7 +94,8 @@ batch_solve_kernel(const BatchJob* __restrict__ jobs, const double* __restrict__
         if (tid < 2) j.red[tid] = __builtin_nan("");
         return;
     }
-    for (int n = tid; n < Npad; n += 256) bs_z[n] = n < N ? y[j.train[n]] - j.mean : 0.0;
+    auto target = [&](int n) { const int r = batch_row(j.train, n, n_rows, bad); return r >= 0 ? y[r] : j.mean; };
+    for (int n = tid; n < Npad; n += 256) bs_z[n] = n < N ? target(n) - j.mean : 0.0;
     __syncthreads();
     for (int i = 0; i < nb; ++i) {
         const double* Lb = L + (size_t)(i * 64) * ld + i * 64;
@@ -164,7 +174,7 @@ batch_solve_kernel(const BatchJob* __restrict__ jobs, const double* __restrict__
         j.alpha[n] = a;
         if (n < N) {
             ld_sum += log(L[(size_t)n * ld + n]);
-            ra = fma(y[j.train[n]] - j.mean, a, ra);
+            ra = fma(target(n) - j.mean, a, ra);
         }
     }
     ld_sum = block_sum(ld_sum, scratch);
@@ -177,7 +187,7 @@ batch_solve_kernel(const BatchJob* __restrict__ jobs, const double* __restrict__
 #define ALABI_BATCH_QT 32
 template <bool GENERIC>
 __global__ void __launch_bounds__(256)
-batch_predict_kernel(const BatchJob* __restrict__ jobs, const double* __restrict__ X, int d, int kernel_type) {
+batch_predict_kernel(const BatchJob* __restrict__ jobs, const double* __restrict__ X, int d, int kernel_type, int n_rows, int* __restrict__ bad) {
     __shared__ double xq[ALABI_MAX_DIM][ALABI_BATCH_QT];
     __shared__ double part[4][ALABI_BATCH_QT];
     const BatchJob& j = jobs[blockIdx.y];
@@ -191,7 +201,8 @@ batch_predict_kernel(const BatchJob* __restrict__ jobs, const double* __restrict
     }
     for (int e = tid; e < d * ALABI_BATCH_QT; e += 256) {
         const int q = e / d, k = e % d;
-        xq[k][q] = q < nq ? X[(size_t)j.val[q0 + q] * d + k] * j.inv_len[k] : 0.0;
+        const int r = q < nq ? batch_row(j.val, q0 + q, n_rows, bad) : -1;
+        xq[k][q] = r >= 0 ? X[(size_t)r * d + k] * j.inv_len[k] : 0.0;
     }
     __syncthreads();
     const KernelFn kf{kernel_type, j.kalpha};
@@ -224,6 +235,36 @@ batch_predict_kernel(const BatchJob* __restrict__ jobs, const double* __restrict
     if (tid < nq) j.mu[q0 + tid] = fma(j.amp, (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]), j.mean);
 }
 
+// Row lists of a k-fold split (sklearn's KFold.split order: ascending rows on both sides) for C candidates at once: fold_of[c][r] = the
+// fold of row r under candidate c's shuffle (-1: in no fold).  One workgroup per (candidate, fold) writes the fold's rows to
+// val_idx[val_off[c k + f] ..) and every other used row to train_idx[train_off[c k + f] ..): an ordered compaction -- each thread
+// owns a contiguous run of rows, a block scan of the two counts gives its write positions.
+__global__ void __launch_bounds__(256)
+batch_fold_lists_kernel(const signed char* __restrict__ fold_of, int n, int k, const long long* __restrict__ train_off,
+                        const long long* __restrict__ val_off, int* __restrict__ train_idx, int* __restrict__ val_idx) {
+    __shared__ int cv[256], ct[256];
+    const int job = blockIdx.x, c = job / k, f = job % k, tid = threadIdx.x;
+    const signed char* fo = fold_of + (size_t)c * n;
+    const int per = (n + 255) / 256, r0 = tid * per, r1 = min(n, r0 + per);
+    int nv = 0, nt = 0;
+    for (int r = r0; r < r1; ++r) { const int v = fo[r]; nv += v == f; nt += (v >= 0) & (v != f); }
+    cv[tid] = nv; ct[tid] = nt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {               // inclusive scan (Hillis-Steele: 8 rounds)
+        const int av = tid >= off ? cv[tid - off] : 0, at = tid >= off ? ct[tid - off] : 0;
+        __syncthreads();
+        cv[tid] += av; ct[tid] += at;
+        __syncthreads();
+    }
+    int* vo = val_idx + val_off[job] + (cv[tid] - nv);
+    int* to = train_idx + train_off[job] + (ct[tid] - nt);
+    for (int r = r0; r < r1; ++r) {
+        const int v = fo[r];
+        if (v == f) *vo++ = r;
+        else if (v >= 0) *to++ = r;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 batch_copy_factor_kernel(const double* __restrict__ L, int ld, int N, double* __restrict__ out) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -242,6 +283,7 @@ struct alabi_gp_batch {
     double* mats = nullptr; size_t mats_bytes = 0;
     double* aux = nullptr; size_t aux_bytes = 0;         // per job: Xt, alpha, dinv, red
     int* info = nullptr; size_t info_cap = 0;
+    int* bad = nullptr;                // [1] a row index out of range was seen
     BatchJob* jobs = nullptr; size_t jobs_cap = 0;
     double* host_red = nullptr; int* host_info = nullptr; size_t host_cap = 0;   // pinned read-back
     CholBatchQueue queue;
@@ -278,6 +320,7 @@ int alabi_gp_batch_destroy(alabi_gp_batch* b) {
     if (b->mats) (void)hipFree(b->mats);
     if (b->aux) (void)hipFree(b->aux);
     if (b->info) (void)hipFree(b->info);
+    if (b->bad) (void)hipFree(b->bad);
     if (b->jobs) (void)hipFree(b->jobs);
     if (b->host_red) (void)hipHostFree(b->host_red);
     if (b->host_info) (void)hipHostFree(b->host_info);
@@ -301,7 +344,7 @@ static int grow(void** p, size_t* have, size_t need, hipStream_t s) {
 }
 
 // one chunk of jobs [c0, c1) whose matrices fit the workspace
-static int run_chunk(alabi_gp_batch* b, const double* X, const double* y, int c0, int c1, const double* hyper, const int* train_idx,
+static int run_chunk(alabi_gp_batch* b, const double* X, const double* y, int n_rows, int c0, int c1, const double* hyper, const int* train_idx,
                      const long long* train_off, const int* val_idx, const long long* val_off, double* mu_val, double* nll, int* status,
                      hipStream_t s) {
     const int B = c1 - c0, d = b->d, db = dim_bucket(d), hs = 4 + d;
@@ -362,9 +405,11 @@ static int run_chunk(alabi_gp_batch* b, const double* X, const double* y, int c0
     if ((st = chol_batch_prepare(b->queue, B, ld.data(), pa.data(), pd.data(), pi.data(), s)) != ALABI_OK) return st;
     const int max_nb = max_npad / 64, max_tiles = max_nb * (max_nb + 1) / 2;
     auto assemble = [&]() {
-        hipLaunchKernelGGL(batch_prepare_kernel, dim3((max_npad + 255) / 256, B), dim3(256), 0, s, b->jobs, X, d, db);
+        hipLaunchKernelGGL(batch_prepare_kernel, dim3((max_npad + 255) / 256, B), dim3(256), 0, s, b->jobs, X, d, db, n_rows, b->bad);
         hipLaunchKernelGGL(batch_assemble_kernel, dim3(max_tiles, B), dim3(256), 0, s, b->jobs, d, b->kernel_type);
     };
+    if (!b->bad) ALABI_HIP_CHECK(hipMalloc(&b->bad, sizeof(int)));
+    ALABI_HIP_CHECK(hipMemsetAsync(b->bad, 0, sizeof(int), s));
     assemble();
     ALABI_LAUNCH_CHECK();
     const char* forced = getenv("ALABI_BATCH_QUEUE");                            // tests: 0 = the launch-per-step factorisation per matrix
@@ -384,16 +429,18 @@ static int run_chunk(alabi_gp_batch* b, const double* X, const double* y, int c0
             if ((st = launch_cholesky_steps(hj[q].A, hj[q].Npad, hj[q].info, hj[q].dinv, s)) != ALABI_OK) return st;
     if ((size_t)max_npad * sizeof(double) > 24 * 1024)                           // beyond the default dynamic LDS limit together with the static arrays
         ALABI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(batch_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 8));
-    hipLaunchKernelGGL(batch_solve_kernel, dim3(B), dim3(256), (size_t)max_npad * sizeof(double), s, b->jobs, y);
+    hipLaunchKernelGGL(batch_solve_kernel, dim3(B), dim3(256), (size_t)max_npad * sizeof(double), s, b->jobs, y, n_rows, b->bad);
     if (max_nval > 0 && mu_val) {
         dim3 grid((max_nval + ALABI_BATCH_QT - 1) / ALABI_BATCH_QT, B);
-        if (b->kernel_type == 0) hipLaunchKernelGGL(batch_predict_kernel<false>, grid, dim3(256), 0, s, b->jobs, X, d, b->kernel_type);
-        else hipLaunchKernelGGL(batch_predict_kernel<true>, grid, dim3(256), 0, s, b->jobs, X, d, b->kernel_type);
+        if (b->kernel_type == 0) hipLaunchKernelGGL(batch_predict_kernel<false>, grid, dim3(256), 0, s, b->jobs, X, d, b->kernel_type, n_rows, b->bad);
+        else hipLaunchKernelGGL(batch_predict_kernel<true>, grid, dim3(256), 0, s, b->jobs, X, d, b->kernel_type, n_rows, b->bad);
     }
     ALABI_LAUNCH_CHECK();
     ALABI_HIP_CHECK(hipMemcpyAsync(b->host_red, red0, (size_t)B * 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     ALABI_HIP_CHECK(hipMemcpyAsync(b->host_info, b->info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+    ALABI_HIP_CHECK(hipMemcpyAsync(&b->host_info[B], b->bad, sizeof(int), hipMemcpyDeviceToHost, s));
     ALABI_HIP_CHECK(hipStreamSynchronize(s));
+    if (b->host_info[B] != 0) { g_last_error = "alabi_gp_batch_fit_predict: a row index lies outside [0, n)"; return ALABI_BAD_ARGUMENT; }
     for (int q = 0; q < B; ++q) {
         status[c0 + q] = b->host_info[q];
         nll[c0 + q] = b->host_info[q] != 0 ? INFINITY
@@ -434,10 +481,19 @@ int alabi_gp_batch_fit_predict(alabi_gp_batch* b, const double* X, const double*
             bytes += Npad * Npad * sizeof(double);
             ++c1;
         }
-        const int st = run_chunk(b, X, y, c0, c1, hyper, train_idx, train_off, val_idx, val_off, mu_val, nll, status, s);
+        const int st = run_chunk(b, X, y, n, c0, c1, hyper, train_idx, train_off, val_idx, val_off, mu_val, nll, status, s);
         if (st != ALABI_OK) return st;
         c0 = c1;
     }
+    return ALABI_OK;
+}
+
+int alabi_cv_fold_lists(const signed char* fold_of, int ncand, int n, int k, const long long* train_off, const long long* val_off,
+                        int* train_idx, int* val_idx, void* stream) {
+    if (!fold_of || ncand <= 0 || n <= 0 || k < 2 || k > 127 || !train_off || !val_off || !train_idx || !val_idx) return ALABI_BAD_ARGUMENT;
+    hipLaunchKernelGGL(batch_fold_lists_kernel, dim3((unsigned)ncand * k), dim3(256), 0, bstream(stream), fold_of, n, k, train_off, val_off,
+                       train_idx, val_idx);
+    ALABI_LAUNCH_CHECK();
     return ALABI_OK;
 }
 

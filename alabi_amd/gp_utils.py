@@ -157,23 +157,28 @@ def _segment_scores(y_val, y_pred, off, scoring, weighted_mse_method="exponentia
 
 def _cv_scores(gp, hyper_rows, fold_of, k_folds, _y, dev, inv, scoring, weighted_mse_method, weighted_mse_factor, batch):
     """Scores [C][k] of C hyper-parameter rows (HipGP.full_hyper) whose folds are given as fold_of [C, n] (fold number of every
-    row, -1 = in no fold): the row lists of all C k jobs are built on the device (ascending rows on both sides, as sklearn's
-    KFold.split yields them), ONE batched library call, one read-back of the held-out means, vectorised scoring."""
+    row, -1 = in no fold): the row lists of all C k jobs are built on the device (alabi_cv_fold_lists: ascending rows on both
+    sides, as sklearn's KFold.split yields them), ONE batched library call, one read-back of the held-out means, vectorised scoring."""
     import torch
     C = len(hyper_rows)
     out = np.full((C, k_folds), np.inf)
     if C == 0:
         return out
-    fo = torch.as_tensor(np.ascontiguousarray(fold_of, dtype=np.int8), device=dev[0].device)           # [C, n]
-    kk = torch.arange(k_folds, dtype=torch.int8, device=fo.device)[None, :, None]
-    is_val = fo[:, None, :] == kk                                                                       # [C, k, n]
-    is_train = (~is_val) & (fo >= 0)[:, None, :]
-    va_dev = is_val.nonzero()[:, 2].to(torch.int32)                                                     # sorted by (c, k, row)
-    tr_dev = is_train.nonzero()[:, 2].to(torch.int32)
+    from . import _lib
+    fold_of = np.ascontiguousarray(fold_of, dtype=np.int8)
+    n = fold_of.shape[1]
     counts = np.stack([(fold_of == q).sum(axis=1) for q in range(k_folds)], axis=1).astype(np.int64)   # [C, k] rows per fold
     used = (fold_of >= 0).sum(axis=1).astype(np.int64)
     va_off = np.zeros(C * k_folds + 1, dtype=np.int64); np.cumsum(counts.ravel(), out=va_off[1:])
     tr_off = np.zeros(C * k_folds + 1, dtype=np.int64); np.cumsum((used[:, None] - counts).ravel(), out=tr_off[1:])
+    d0 = dev[0].device
+    fo = torch.as_tensor(fold_of, device=d0)                                                            # [C, n]
+    tr_dev = torch.empty(max(int(tr_off[-1]), 1), dtype=torch.int32, device=d0)
+    va_dev = torch.empty(max(int(va_off[-1]), 1), dtype=torch.int32, device=d0)
+    tr_off_dev, va_off_dev = torch.as_tensor(tr_off, device=d0), torch.as_tensor(va_off, device=d0)   # (named: they must outlive the call)
+    _lib.check(_lib.lib().alabi_cv_fold_lists(_lib.ptr(fo), C, n, k_folds, _lib.ptr(tr_off_dev), _lib.ptr(va_off_dev), _lib.ptr(tr_dev),
+                                              _lib.ptr(va_dev), _lib.current_stream()), "alabi_cv_fold_lists")
+    tr_dev, va_dev = tr_dev[:int(tr_off[-1])], va_dev[:int(va_off[-1])]
     hyper = np.repeat(np.asarray(hyper_rows, dtype=np.float64), k_folds, axis=0)
     ll, status, mu, off = batch.fit_predict_indexed(dev[0], dev[1], hyper, tr_dev, tr_off, va_dev, va_off)
     if mu is None:

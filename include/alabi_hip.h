@@ -86,6 +86,12 @@ int alabi_gp_batch_fit_predict(alabi_gp_batch* batch, const double* X, const dou
                                const double* hyper /* host */, const int* train_idx, const long long* train_off /* host */,
                                const int* val_idx, const long long* val_off /* host */, double* mu_val,
                                double* nll /* host */, int* status /* host */, void* stream);
+/* The row lists of a k-fold split for `ncand` candidates at once (alabi/gp_utils.py:538: sklearn KFold(shuffle=True).split yields
+ * ascending train and validation rows): fold_of [ncand, n] int8 = the fold of every row under each candidate's shuffle (-1: unused
+ * row); job c k + f gets fold f's rows in val_idx[val_off[job] ..) and the other used rows in train_idx[train_off[job] ..).  All
+ * arrays on the device (offsets int64 [ncand k + 1], computed by the caller from the fold sizes). */
+int alabi_cv_fold_lists(const signed char* fold_of, int ncand, int n, int k, const long long* train_off,
+                        const long long* val_off, int* train_idx, int* val_idx, void* stream);
 /* Factor [N,N] (zeros above the diagonal) / alpha [N] of a job of the LAST chunk processed (tests: bit-identity with the
  * single-matrix path); ALABI_BAD_ARGUMENT for a job of an earlier chunk. */
 int alabi_gp_batch_get_factor(alabi_gp_batch* batch, int job, double* L_out, void* stream);

@@ -148,3 +148,58 @@ def test_cv_fold_scores_vs_reference_worker(scaler):
             want = g[f"cv_{scaler}_{scoring}_{ci}"]
             assert np.all(np.isfinite(got))
             np.testing.assert_allclose(got, want, rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("C,n,k", [(1, 7, 2), (3, 157, 5), (40, 2000, 5), (2, 12288, 10), (5, 300, 127)])
+def test_cv_fold_lists_are_sklearns_ascending_row_lists(C, n, k):
+    """alabi_cv_fold_lists (the row lists of every (candidate, fold) job, built on the device) against NumPy: fold f's rows ascending
+    in the validation list, every other used row ascending in the training list, rows marked -1 in neither (gp_utils.py:538:
+    KFold.split's order)."""
+    import torch
+    from alabi_amd import _lib
+    rng = np.random.RandomState(C * 1000 + n + k)
+    fold_of = rng.randint(-1 if n > 50 else 0, k, size=(C, n)).astype(np.int8)
+    counts = np.stack([(fold_of == q).sum(axis=1) for q in range(k)], axis=1).astype(np.int64)
+    used = (fold_of >= 0).sum(axis=1).astype(np.int64)
+    va_off = np.zeros(C * k + 1, dtype=np.int64); np.cumsum(counts.ravel(), out=va_off[1:])
+    tr_off = np.zeros(C * k + 1, dtype=np.int64); np.cumsum((used[:, None] - counts).ravel(), out=tr_off[1:])
+    dev = torch.device("cuda")
+    tr = torch.full((int(tr_off[-1]) + 1,), -7, dtype=torch.int32, device=dev)
+    va = torch.full((int(va_off[-1]) + 1,), -7, dtype=torch.int32, device=dev)
+    fo_d, tr_off_d, va_off_d = torch.as_tensor(fold_of, device=dev), torch.as_tensor(tr_off, device=dev), torch.as_tensor(va_off, device=dev)
+    st = _lib.lib().alabi_cv_fold_lists(_lib.ptr(fo_d), C, n, k, _lib.ptr(tr_off_d), _lib.ptr(va_off_d), _lib.ptr(tr), _lib.ptr(va),
+                                        _lib.current_stream())
+    torch.cuda.synchronize()
+    assert st == 0
+    tr, va = tr.cpu().numpy(), va.cpu().numpy()
+    assert tr[-1] == -7 and va[-1] == -7                      # nothing written past the end
+    for c in range(C):
+        for f in range(k):
+            j = c * k + f
+            np.testing.assert_array_equal(va[va_off[j]:va_off[j + 1]], np.flatnonzero(fold_of[c] == f))
+            np.testing.assert_array_equal(tr[tr_off[j]:tr_off[j + 1]], np.flatnonzero((fold_of[c] >= 0) & (fold_of[c] != f)))
+
+
+def test_batch_rejects_row_indices_out_of_range():
+    """Row lists handed to alabi_gp_batch_fit_predict are the caller's: an index outside [0, n) must come back as ALABI_BAD_ARGUMENT,
+    never reach an address."""
+    import torch
+    from alabi_amd import _lib
+    from alabi_amd.gp_batch import HipGPBatch
+    X, y, hyper, train, val = _jobs(300, 3, 1, [200, 150])
+    dev = torch.device("cuda")
+    Xd, yd = torch.as_tensor(X, device=dev), torch.as_tensor(y, device=dev)
+    bt = HipGPBatch(3)
+    tr = torch.as_tensor(np.concatenate(train).astype(np.int32), device=dev)
+    va = torch.as_tensor(np.concatenate(val).astype(np.int32), device=dev)
+    tr_off = np.array([0, 200, 350], dtype=np.int64); va_off = np.array([0, len(val[0]), len(val[0]) + len(val[1])], dtype=np.int64)
+    bt.fit_predict_indexed(Xd, yd, hyper, tr, tr_off, va, va_off)                      # fine as it is
+    for which, poison in (("train", 300), ("train", -5), ("val", 10 ** 6)):
+        t2, v2 = tr.clone(), va.clone()
+        (t2 if which == "train" else v2)[7] = poison
+        with pytest.raises(_lib.AlabiHipError) as ei:
+            bt.fit_predict_indexed(Xd, yd, hyper, t2, tr_off, v2, va_off)
+        assert ei.value.status == _lib.BAD_ARG
+    ll, st, mu, off = bt.fit_predict_indexed(Xd, yd, hyper, tr, tr_off, va, va_off)    # the handle is still usable
+    assert np.all(st == 0) and np.all(np.isfinite(ll))
+    bt.close()
