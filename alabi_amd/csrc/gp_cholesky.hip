@@ -1715,6 +1715,10 @@ int launch_cholesky(alabi_gp* gp, hipStream_t s) { return launch_cholesky_steps(
 //     ~ P * nlists lower triangles instead of all B;
 //   * within a slot the matrices closest to their end come first (their steps are short and chain-bound).
 // Each matrix keeps the order of its own list, so every list remains a topological order.
+// (Round 4, measured and not kept -- tools/experiments/chol_batch_trsm3_tasks.patch: two or three panel tiles per TRSM task, one wave's
+// slab recurrence per tile side by side, bit-identical: 500 matrices of N = 1600 28.5-29.2 ms with one tile per task in that build,
+// 27.6-27.9 with two / three -- but the build without the extra task type does 27.5-28.0: the new code path costs the kernel 15 more
+// spilled registers, which takes back what the TRSM tasks gain; N = 8000 4.50 -> 4.38 ms per fit.)
 // ALABI_BATCH_GK: block columns per group, ALABI_BATCH_LEFT=0: the single-matrix list instead.  Measured (tools/prof_batch_cv.py, 500
 // matrices of N = 1600 per call, everything included): the single-matrix list 46.6 ms; this one 34.3 (gk 4), 31.9 (8), 31.8 (10), 32.1 (12),
 // 35.5 (16), 36.9 (32 = left-looking) -- profiles/r04_batch_sweeps.txt

@@ -11,7 +11,7 @@ from alabi_amd.workloads import make_config
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 sweep = len(sys.argv) > 2 and sys.argv[2] == "sweep"
 cfg_name = sys.argv[3] if len(sys.argv) > 3 else "C3"
-cfg = make_config(cfg_name)
+cfg = make_config(cfg_name.rstrip("x"))
 X, y, h, d = cfg["X"], cfg["y"], cfg["hyper"], cfg["d"]
 n = len(X)
 rng = np.random.RandomState(0)
