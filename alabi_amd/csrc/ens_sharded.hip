@@ -258,10 +258,13 @@ static int run_sharded(alabi_ens* e, alabi_comm* c, double* coords, double* logp
         ALABI_HIP_CHECK(hipMemsetAsync(c->shist, 0, need * sizeof(double), s));   // slots beyond a rank's share travel in the all-gather
         c->shist_cap = need;
     }
-    // a graph of one full chunk, where everything it enqueues can be captured (RCCL, or no collective at all); the host callback
-    // of the test rig cannot
-    const char* genv = getenv("ALABI_ENS_GRAPH");
-    const bool want_graph = s != nullptr && !c->fn && !(genv && genv[0] == '0');
+    // A graph of one full chunk, where everything it enqueues can be captured (RCCL, or no collective at all; the host callback of the
+    // test rig cannot).  OPT-IN (ALABI_ENS_SHARD_GRAPH=1) since round 4, when the replay first actually ran (before, the run was handed
+    // the null stream, which cannot capture): replaying the ~4000 nodes of a chunk is SLOWER than enqueueing them -- one rank, C3
+    // 6.27 vs 5.83 us per half step, C4 11.7 vs 10.5-11.2 (profiles/r04_sharded_one_rank.txt): the half-step kernel runs 5-10 us, so
+    // the host is never the bound and the graph only adds its per-node cost.
+    const char* genv = getenv("ALABI_ENS_SHARD_GRAPH");
+    const bool want_graph = s != nullptr && !c->fn && genv && genv[0] == '1';
     if ((st = ens_sync_consts(e, s)) != ALABI_OK) return st;      // (a host copy + synchronisation: not inside a capture)
     long long done = 0;
     while (done < nsteps) {

@@ -95,7 +95,9 @@ def test_sharded_run_single_rank_and_rccl_loads(monkeypatch):
     chain2, _, _, nacc2 = run2.run(torch.as_tensor(p0, device="cuda"), nsteps, thin_by=3)
     torch.cuda.synchronize()
     assert np.array_equal(chain2.cpu().numpy(), ref.get_chain()) and np.array_equal(nacc2.cpu().numpy(), nacc.cpu().numpy())
-    # two full chunks (1024 steps each: the captured graph is replayed) plus a remainder, thinned chain, RCCL communicator
+    # two full chunks (1024 steps each) plus a remainder, thinned chain, RCCL communicator; with the graph opted in
+    # (ALABI_ENS_SHARD_GRAPH=1: measured slower than eager launches, hence not the default) the chunks ARE replayed
+    monkeypatch.setenv("ALABI_ENS_SHARD_GRAPH", "1")
     ref3 = EnsembleSampler(W, 4, gp, y, bounds, seed=5); ref3.run_mcmc(p0, 2100, thin_by=7)
     s3 = EnsembleSampler(W, 4, gp, y, bounds, seed=5)
     run3 = ShardedRun(s3)
@@ -110,11 +112,11 @@ def test_sharded_run_single_rank_and_rccl_loads(monkeypatch):
     ref4 = EnsembleSampler(W, 4, gp, y, bounds, seed=5, logp_affine=(2.0, -1.0)); ref4.run_mcmc(p0, 1100)
     chain4, _, _, _ = ShardedRun(s4).run(torch.as_tensor(p0, device="cuda"), 1100)
     assert np.array_equal(chain4.cpu().numpy(), ref4.get_chain())
-    monkeypatch.setenv("ALABI_ENS_GRAPH", "0")              # and without the graph: the same chain, every chunk enqueued eagerly
+    monkeypatch.delenv("ALABI_ENS_SHARD_GRAPH")             # the default: the same chain, every chunk enqueued eagerly
     run5 = ShardedRun(EnsembleSampler(W, 4, gp, y, bounds, seed=5))
     chain5, _, _, _ = run5.run(torch.as_tensor(p0, device="cuda"), 2100, thin_by=7)
-    assert np.array_equal(chain5.cpu().numpy(), ref3.get_chain()) and run5.stats()["graph_replays"] == 0
-    monkeypatch.delenv("ALABI_ENS_GRAPH")
+    st5 = run5.stats()
+    assert np.array_equal(chain5.cpu().numpy(), ref3.get_chain()) and st5["graph_replays"] == 0 and st5["eager_chunks"] == 3
     del run2
     buf = C.create_string_buffer(128)
     _lib.check(_lib.lib().alabi_dist_unique_id(buf), "alabi_dist_unique_id")

@@ -13,7 +13,7 @@ for name in ("C3", "C4"):
     gp = HipGP(cfg["d"], h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); gp.compute(cfg["X"])
     for rccl in ("0", "1"):
         for graph in ("1", "0"):
-            os.environ["ALABI_DIST_FORCE_RCCL"] = rccl; os.environ["ALABI_ENS_GRAPH"] = graph
+            os.environ["ALABI_DIST_FORCE_RCCL"] = rccl; os.environ["ALABI_ENS_SHARD_GRAPH"] = graph
             s = EnsembleSampler(cfg["W"], cfg["d"], gp, cfg["y"], cfg["bounds"], seed=3)
             run = ShardedRun(s)
             c0 = torch.as_tensor(cfg["p0"], device="cuda")
@@ -22,6 +22,7 @@ for name in ("C3", "C4"):
             best = 1e9
             for _ in range(3):
                 t0 = time.perf_counter(); run.run(c0, steps, store=True); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+            st = run.stats()
             print(f"{name} W={cfg['W']} one rank, RCCL communicator={rccl} graph={graph}: {1e6 * best / (2 * steps):.2f} us per half step, "
-                  f"{cfg['W'] * steps / best:.3e} samples/s", flush=True)
+                  f"{cfg['W'] * steps / best:.3e} samples/s (chunks replayed {st['graph_replays']}, eager {st['eager_chunks']})", flush=True)
             del run, s
