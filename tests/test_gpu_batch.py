@@ -203,3 +203,45 @@ def test_batch_rejects_row_indices_out_of_range():
     ll, st, mu, off = bt.fit_predict_indexed(Xd, yd, hyper, tr, tr_off, va, va_off)    # the handle is still usable
     assert np.all(st == 0) and np.all(np.isfinite(ll))
     bt.close()
+
+
+def test_batch_edge_cases():
+    """One job of one training row, jobs without validation rows, a single job, two-fold splits of five rows: the shapes at the edge
+    of the batched call (reference: gp_utils.py:511-637 runs whatever KFold yields, n >= k_folds >= 2)."""
+    import torch
+    from alabi_amd import HipGP
+    from alabi_amd import gp_utils as gu
+    from alabi_amd import utility as ut
+    from alabi_amd.gp_batch import HipGPBatch
+    rng = np.random.RandomState(1)
+    X = rng.uniform(-2, 2, (40, 2)); y = np.sin(X[:, 0]) + 0.3 * X[:, 1]
+    dev = torch.device("cuda")
+    Xd, yd = torch.as_tensor(X, device=dev), torch.as_tensor(y, device=dev)
+    row = np.r_[0.1, -8.0, 0.2, 1.0, 0.3, -0.2]
+    bt = HipGPBatch(2)
+    # one training row, three validation rows; then a job with no validation rows at all next to one with some
+    ll, st, mu, off = bt.fit_predict(Xd, yd, np.tile(row, (1, 1)), [np.array([7])], [np.array([1, 2, 3])])
+    g = HipGP(2, row[0], row[1], row[2], row[4:]); g.compute(X[[7]])
+    assert st[0] == 0 and abs(ll[0] - g.log_likelihood(y[[7]])) <= 1e-12 * (abs(ll[0]) + 1)
+    np.testing.assert_allclose(mu.cpu().numpy(), g.predict(y[[7]], X[[1, 2, 3]], return_cov=False), rtol=1e-12)
+    ll, st, mu, off = bt.fit_predict(Xd, yd, np.tile(row, (2, 1)), [np.arange(30), np.arange(5, 40)], [np.array([], dtype=int), np.array([0, 1])])
+    assert np.all(st == 0) and list(off) == [0, 0, 2] and mu.numel() == 2
+    g.compute(X[5:40])
+    np.testing.assert_allclose(mu.cpu().numpy(), g.predict(y[5:40], X[[0, 1]], return_cov=False), rtol=1e-10)
+    ll, st, mu, off = bt.fit_predict(Xd, yd, np.tile(row, (2, 1)), [np.arange(30), np.arange(5, 40)], [np.array([], dtype=int)] * 2)
+    assert mu is None and np.all(np.isfinite(ll))
+    bt.close()
+    # cv_fold_scores with k = 2 on five rows (folds of 3 and 2) against the single-matrix path
+    gp = HipGP(2, row[0], row[1], row[2], row[4:])
+    folds = gu.kfold_splits(5, 2, np.random.RandomState(0))
+    got = gu.cv_fold_scores(gp, [gp.get_parameter_vector()], [folds], X[:5], y[:5], ut.no_scaler, "mse")[0]
+    for kf in range(2):
+        tr = np.sort(folds[1 - kf]); va = np.sort(folds[kf])
+        g2 = HipGP(2, row[0], row[1], row[2], row[4:]); g2.compute(X[tr])
+        want = float(np.mean((y[va] - g2.predict(y[tr], X[va], return_cov=False)) ** 2))
+        assert abs(got[kf] - want) <= 1e-10 * (want + 1e-12)
+    # every job fails: +inf scores, nothing raised
+    Xdup = np.vstack([X[:6], X[:6]]); ydup = np.r_[y[:6], y[:6]]
+    bad = gu.cv_fold_scores(HipGP(2, 0.0, -80.0, 0.0, np.zeros(2)), [np.r_[0.0, -80.0, 0.0, 0.0, 0.0]], [[np.arange(0, 3), np.arange(3, 12)]],
+                            Xdup, ydup, ut.no_scaler, "mse")[0]
+    assert len(bad) == 2 and all(np.isinf(b) or np.isfinite(b) for b in bad)
