@@ -685,11 +685,14 @@ def main():
                 t_cfg = time.perf_counter()
                 extras["configs"] = config_extras()
                 extras["configs_wall_s"] = time.perf_counter() - t_cfg
-                t_cfg = time.perf_counter()
-                extras["end_to_end"] = end_to_end_extras(cfg)
-                extras["end_to_end"]["wall_s"] = time.perf_counter() - t_cfg
-                if cpu_e2e is not None:
-                    extras["end_to_end"]["cpu_baseline"] = cpu_e2e
+                if world == 1:
+                    # (one rank only: under a process group SurrogateModel's init_gp / active_train are COLLECTIVE calls -- candidates
+                    # dealt over ranks, sharded candidate scan -- and the other ranks of a multi-GPU bench run do not make them)
+                    t_cfg = time.perf_counter()
+                    extras["end_to_end"] = end_to_end_extras(cfg)
+                    extras["end_to_end"]["wall_s"] = time.perf_counter() - t_cfg
+                    if cpu_e2e is not None:
+                        extras["end_to_end"]["cpu_baseline"] = cpu_e2e
             out["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             out["parity_gate"] = parity_gate(cfg, gp, y_dev, cpu_chain, args)
