@@ -161,9 +161,10 @@ def test_batched_cholesky_matrix_list_is_a_topological_order(gk, update4, monkey
             assert tiles == (nb - 1) * (nb - 2) // 2 + max(nb - 2, 0)     # (i, j) with i > j >= 1, and the diagonal tiles from (2, 2) on
 
 
+@pytest.mark.parametrize("phases", ["1", "0"])
 @pytest.mark.parametrize("left", ["1", "0"])
 @pytest.mark.parametrize("nlists,window", [(1, 0), (1, 3), (3, 2), (8, 3), (8, 0), (8, 100)])
-def test_batched_cholesky_queue_keeps_every_matrix_in_order(nlists, window, left, monkeypatch):
+def test_batched_cholesky_queue_keeps_every_matrix_in_order(nlists, window, left, phases, monkeypatch):
     """The interleaved queue of the batched factorisation (alabi/gp_utils.py:511-700: candidates x folds): every matrix lives in
     exactly one list, its tasks appear there in the order of its own single-matrix list (so each list is a topological order and a
     workgroup only waits for tasks in front of the one it drew), nothing is lost or duplicated -- for mixed sizes, any number of
@@ -172,6 +173,7 @@ def test_batched_cholesky_queue_keeps_every_matrix_in_order(nlists, window, left
     for k in ("ALABI_CHOL_GK", "ALABI_CHOL_NEAR", "ALABI_CHOL_W8", "ALABI_CHOL_UPDATE2", "ALABI_CHOL_UPDATE4", "ALABI_BATCH_GK"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("ALABI_BATCH_LEFT", left)
+    monkeypatch.setenv("ALABI_BATCH_PHASES", phases)                 # slot order: phase by phase over the matrices / matrix by matrix
     nbs = [25, 25, 26, 3, 25, 16, 40, 25, 1, 5, 25, 2, 33, 25, 25, 7, 25]
     B = len(nbs)
     arr = (ctypes.c_int * B)(*nbs)
