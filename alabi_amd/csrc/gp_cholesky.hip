@@ -1764,22 +1764,26 @@ static int chol_batch_build(const std::vector<int>& nbs, int nlists, int window,
             if (start[r] + steps > last_slot) last_slot = start[r] + steps;
         }
         // Inside a slot the tasks go PHASE by phase over the active matrices -- every matrix's CHAIN, then every matrix's panel solves,
-        // then every matrix's updates -- not matrix by matrix: the updates of a step wait for the CHAIN and the panel solves of the SAME
-        // step, which were drawn moments before them; with the other matrices' tasks in between they are finished when a workgroup
-        // reaches the updates, instead of holding it for up to a CHAIN's 17 us (ALABI_BATCH_PHASES=0: matrix by matrix).  A matrix's own
-        // tasks keep their order (its step is CHAIN, panel solves, updates in that order already).
+        // then every matrix's catch-up updates (what the NEXT step's CHAIN and panel solves read), then every matrix's grouped updates
+        // -- not matrix by matrix: the updates of a step wait for the CHAIN and the panel solves of the SAME step, drawn moments before
+        // them, and the next CHAIN waits for this step's catch-ups; with the other matrices' tasks in between, a task's inputs are
+        // finished when a workgroup reaches it instead of holding that workgroup for up to a CHAIN's 17 us (ALABI_BATCH_PHASES=0:
+        // matrix by matrix; =3: without the split of the updates).  A matrix's own tasks keep their order (its step is CHAIN, panel
+        // solves, catch-ups, groups in that order already).
         const char* pe = getenv("ALABI_BATCH_PHASES");
-        const bool by_phase = !(pe && pe[0] == '0');
+        const int nphase = (pe && pe[0] == '0') ? 1 : ((pe && pe[0] == '3') || !chol_batch_left()) ? 3 : 4;
         for (int t = 0; t < last_slot; ++t)
-            for (int phase = 0; phase < (by_phase ? 3 : 1); ++phase)
+            for (int phase = 0; phase < nphase; ++phase)
                 for (size_t r = 0; r < mem.size(); ++r) {                           // lower rank = started earlier = closer to its end
                     const int b = mem[r], st = t - start[r];
                     if (st < 0 || st >= nbs[b]) continue;
                     const auto& e = per_nb[nbs[b]];
                     for (int x = e.second[st]; x < e.second[st + 1]; ++x) {
                         CholTask c = e.first[x];
-                        const int ty = c.type & 255, ph = ty == 0 ? 0 : ty == 1 ? 1 : 2;
-                        if (by_phase && ph != phase) continue;
+                        const int ty = c.type & 255, k = st - 1;                    // step st factorises block column k + 1 = st
+                        int ph = ty == 0 ? 0 : ty == 1 ? 1 : 2;
+                        if (ph == 2 && nphase == 4 && !(c.j == k + 1 || (c.i == c.j && c.j == k + 2))) ph = 3;   // not a catch-up: a grouped update
+                        if (nphase > 1 && ph != phase) continue;
                         c.type |= b << 16;
                         out.push_back(c);
                     }
@@ -1836,7 +1840,7 @@ int chol_batch_prepare(CholBatchQueue& q, int B, const int* ld, double* const* A
         int gk, near;
         chol_task_shape(nbs[0], &gk, &near);
         const char* e4 = getenv("ALABI_CHOL_UPDATE4");
-        shape_sig = (chol_batch_left() ? 1 << 20 : 0) + ((getenv("ALABI_BATCH_PHASES") && getenv("ALABI_BATCH_PHASES")[0] == '0') ? 1 << 21 : 0) + chol_batch_gk() * 4096 + gk * 64 + near * 4 + (e4 ? (e4[0] == '1' ? 1 : 3) : 0);
+        shape_sig = (chol_batch_left() ? 1 << 20 : 0) + ((getenv("ALABI_BATCH_PHASES") ? (getenv("ALABI_BATCH_PHASES")[0] & 7) : 7) << 21) + chol_batch_gk() * 4096 + gk * 64 + near * 4 + (e4 ? (e4[0] == '1' ? 1 : 3) : 0);
     }
     if (!(q.tasks && q.nbs == nbs && q.nlists == nlists && q.window == window && q.shape_sig == shape_sig)) {
         std::vector<CholTask> t;

@@ -161,7 +161,7 @@ def test_batched_cholesky_matrix_list_is_a_topological_order(gk, update4, monkey
             assert tiles == (nb - 1) * (nb - 2) // 2 + max(nb - 2, 0)     # (i, j) with i > j >= 1, and the diagonal tiles from (2, 2) on
 
 
-@pytest.mark.parametrize("phases", ["1", "0"])
+@pytest.mark.parametrize("phases", ["4", "3", "0"])
 @pytest.mark.parametrize("left", ["1", "0"])
 @pytest.mark.parametrize("nlists,window", [(1, 0), (1, 3), (3, 2), (8, 3), (8, 0), (8, 100)])
 def test_batched_cholesky_queue_keeps_every_matrix_in_order(nlists, window, left, phases, monkeypatch):
