@@ -73,6 +73,7 @@ SIGNATURES = {
     "alabi_ens_group_plan": (_i, [_vp, _pi]),
     "alabi_ens_lnprob": (_i, [_vp, _vp, _vp, _vp]),
     "alabi_ens_run": (_i, [_vp, _vp, _vp, _ll, _ll, _i, _d, _vp, _vp, _vp, _vp]),
+    "alabi_chain_autocorr": (_i, [_vp, _ll, _i, _i, _vp, _vp]),
     "alabi_ens_draw": (_i, [_vp, _ll, _i, _d, _vp]),
     "alabi_ens_half_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "alabi_dist_unique_id": (_i, [_vp]),

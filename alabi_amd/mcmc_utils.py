@@ -3,9 +3,11 @@
 ``estimate_burnin`` mirrors alabi/mcmc_utils.py:15-72 (iburn = int(2 max tau),
 ithin = max(int(0.5 min tau), 1), tau from ``sampler.get_autocorr_time(tol=0)``).
 ``integrated_time`` restates emcee 3 ``autocorr.integrated_time`` (Sokal window, ACF averaged
-over walkers); chains above 64 MB are transformed on the device that holds them, so that only
-``ndim`` numbers come back; shorter ones on the host, where the FFT has no
-run-time compilation cost.
+over walkers).  A chain that lives on the GPU is transformed there by the library's own kernels
+(``alabi_chain_autocorr``: four-step transforms in LDS, alabi_amd/csrc/chain_acf.hip) and only the
+walker-averaged autocorrelation function [ndim, nsteps] comes back -- no FFT
+library: rocFFT compiles kernels at run time for every new transform length (1-2 s each on MI355X), and
+the length follows the number of steps of the run.  Host arrays use NumPy's real FFT.
 """
 from __future__ import annotations
 
@@ -48,10 +50,18 @@ def integrated_time(x, c=5, tol=50, quiet=False, has_walkers=True):
         x = x[:, :, None]
     n_t, n_w, n_d = x.shape
     n = _next_pow_two(n_t)
-    # The first FFT of a process on the GPU pays rocFFT's run-time kernel compilation (2.9 s on MI355X, then 1 ms per call);
-    # chains of up to 64 MB are therefore transformed on the host with NumPy's real FFT along a contiguous time axis
-    # (5 MB: about 10 ms), longer ones stay on the device (ALABI_FFT_HOST_MAX, in elements, moves the switch).
-    if (not x.is_cuda) or x.numel() <= int(os.environ.get("ALABI_FFT_HOST_MAX", 8_000_000)):
+    # Device chains: the library's transforms (any length up to 2^21 steps, no run-time compilation).  Host chains, and device chains
+    # of at most ALABI_FFT_HOST_MAX elements (default 0: none), use NumPy's real FFT along a contiguous time axis.
+    native = x.is_cuda and n_t <= (1 << 21) and x.numel() > int(os.environ.get("ALABI_FFT_HOST_MAX", 0)) \
+        and os.environ.get("ALABI_ACF_NATIVE", "1") != "0"
+    if native:
+        from . import _lib
+        xc = x.contiguous()
+        acf = torch.empty((n_d, n_t), dtype=torch.float64, device=x.device)
+        _lib.check(_lib.lib().alabi_chain_autocorr(_lib.ptr(xc), n_t, n_w, n_d, _lib.ptr(acf), _lib.current_stream()),
+                   "alabi_chain_autocorr")
+        taus = (2.0 * np.cumsum(acf.cpu().numpy(), axis=-1) - 1.0).T                # [n_t, n_d]
+    elif (not x.is_cuda) or x.numel() <= int(os.environ.get("ALABI_FFT_HOST_MAX", 0)):
         xh = np.ascontiguousarray(np.moveaxis(x.cpu().numpy(), 0, -1))           # [n_w, n_d, n_t]
         xh = xh - xh.mean(axis=-1, keepdims=True)
         f = np.fft.rfft(xh, n=2 * n, axis=-1)
@@ -59,7 +69,7 @@ def integrated_time(x, c=5, tol=50, quiet=False, has_walkers=True):
         acf = acf / acf[..., :1]
         fmean = acf.mean(axis=0)                                                 # average over walkers -> [n_d, n_t]
         taus = (2.0 * np.cumsum(fmean, axis=-1) - 1.0).T                         # [n_t, n_d]
-    else:
+    else:                                             # more than 2^21 steps on the device (or ALABI_ACF_NATIVE=0): torch.fft = rocFFT
         xc = x - x.mean(dim=0, keepdim=True)
         f = torch.fft.fft(xc, n=2 * n, dim=0)
         acf = torch.fft.ifft(f * torch.conj(f), dim=0)[:n_t].real

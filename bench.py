@@ -250,6 +250,15 @@ def end_to_end_extras(cfg):
         res["active_train_iter_ms"] = 1e3 * dt / niter
         res["active_train_iter_detail"] = "C3 + 14 points: scan 16384 candidates + 4 zoom stages + polish, lnlike call, append; no hyper-fit"
         res["active_train_appended"] = int(getattr(sm.gp, "appended", 0))
+        # the reference's default sampling call (nsteps = 5e4, core.py:2108) with 256 walkers: sampling + burn-in / thinning estimate
+        # (integrated autocorrelation time of the 1 GB chain on the device) + flattening + the samples file
+        times = []
+        for rep in range(2):
+            times.append(timed(lambda: sm.run_emcee(nwalkers=256, nsteps=50_000, min_ess=0))[0])
+        res["run_emcee_5e4_steps_s"] = min(times)
+        res["run_emcee_5e4_steps_s_first_call"] = times[0]
+        res["run_emcee_sampling_s"] = float(sm.emcee_sampler.last_run_seconds)
+        res["run_emcee_kept_samples"] = int(sm.emcee_samples.shape[0])
         del sm
         torch.cuda.empty_cache()
     except Exception as ex:  # noqa: BLE001

@@ -232,6 +232,13 @@ int alabi_ens_run(alabi_ens* ens, double* coords, double* logp, long long step0,
                   long long nsteps, int thin_by, double a, double* chain, double* chain_logp,
                   long long* n_accept, void* stream);
 
+/* sampler.get_autocorr_time(tol=0) -- alabi/mcmc_utils.py:45, alabi/core.py:2387 (emcee.autocorr.integrated_time): the FFT part.
+ * chain [n_t, n_w, n_d] (device, as alabi_ens_run stores it) -> acf_mean [n_d, n_t] (device): for every dimension the mean over
+ * the walkers of acf = IFFT(|FFT(x - mean(x), 2 n)|^2)[:n_t] / acf[0], n = the next power of two >= n_t.  Hand-written four-step
+ * transforms in LDS (alabi_amd/csrc/chain_acf.hip): no run-time kernel compilation per transform length.  n_t <= 2^21.  The Sokal
+ * window and tau = 2 cumsum(acf) - 1 follow on the host (alabi_amd/mcmc_utils.py).  Synchronises the stream. */
+int alabi_chain_autocorr(const double* chain, long long n_t, int n_w, int n_d, double* acf_mean, void* stream);
+
 /* Multi-GPU building blocks for ONE sharded ensemble (n_ensembles == 1; alabi_amd/dist.py
  * drives them around an RCCL all-gather): draw the proposal records of steps
  * [step0, step0+nsteps) into the handle, then apply one HALF step (split 0 or 1 of local
