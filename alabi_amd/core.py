@@ -148,7 +148,27 @@ class SurrogateModel(object):
     def __getstate__(self):
         state = self.__dict__.copy()
         state["pool"] = None
+        if state.get("_emcee_full_src") is not None:          # the saved model carries the array itself, as the reference's does
+            state["_emcee_full"] = self.emcee_samples_full
+            state["_emcee_full_src"] = None
         return state
+
+    @property
+    def emcee_samples_full(self):
+        """The whole chain [nsteps, nwalkers, ndim] in theta coordinates (core.py:2377).  Materialised on first access: at the
+        reference's default 5e4 steps x 256 walkers it is a 1 GB copy out of HBM plus an un-scaling pass on the host (0.5 s, three
+        times the sampling itself), which run_emcee should not charge to callers that never look at it."""
+        if getattr(self, "_emcee_full", None) is None and getattr(self, "_emcee_full_src", None) is not None:
+            sampler, t_add, t_mult = self._emcee_full_src
+            self._emcee_full = (np.asarray(sampler.get_chain()) - t_add) / t_mult
+            self._emcee_full_src = None
+        if getattr(self, "_emcee_full", None) is None:
+            raise AttributeError("emcee_samples_full: run_emcee has not been called")
+        return self._emcee_full
+
+    @emcee_samples_full.setter
+    def emcee_samples_full(self, value):
+        self._emcee_full, self._emcee_full_src = value, None
 
     def save(self):
         """Pickle the model (write-to-temp then rename, alabi/core.py:371-392)."""
@@ -1071,7 +1091,7 @@ class SurrogateModel(object):
             p0 = self.emcee_sampler.get_last_sample().coords
             kw["seed"] = self._seed() + (rank if replicas else 0)
         self.emcee_samples = np.vstack(all_chains) if len(all_chains) > 1 else all_chains[0]
-        self.emcee_samples_full = to_theta(self.emcee_sampler.get_chain())
+        self._emcee_full, self._emcee_full_src = None, (self.emcee_sampler, t_add, t_mult)     # emcee_samples_full: on first access
         self.iburn, self.ithin = cur_iburn, cur_ithin
         self.burn, self.thin = cur_burn, cur_thin
         self.emcee_runtime = sum(all_times)

@@ -361,6 +361,7 @@ class EnsembleSampler:
         self._chains, self._chain_lps, self._thins = [], [], []
         self._naccept.zero_()
         self.iteration = 0
+        self._tau_memo = None
 
     # -------------------------------------------------------------------------- results
     def get_chain_device(self, discard=0, thin=1, flat=False, log_prob=False):
@@ -389,5 +390,13 @@ class EnsembleSampler:
         return self._naccept.cpu().numpy() / float(max(self.iteration, 1))
 
     def get_autocorr_time(self, discard=0, thin=1, **kwargs):
+        # run_emcee asks twice for the same numbers (estimate_burnin, then the summary: mcmc_utils.py:45, core.py:2387): remembered
+        # until the chain grows or is reset
+        key = (self.iteration, len(self._chains), int(discard), int(thin), tuple(sorted(kwargs.items())))
+        memo = getattr(self, "_tau_memo", None)
+        if memo is not None and memo[0] == key:
+            return memo[1].copy()
         x = self.get_chain_device(discard=discard, thin=thin)
-        return thin * integrated_time(x, **kwargs)
+        tau = thin * integrated_time(x, **kwargs)
+        self._tau_memo = (key, np.array(tau, copy=True))
+        return tau
