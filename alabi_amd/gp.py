@@ -169,7 +169,7 @@ class HipGP:
 
     def __getstate__(self):
         st = self.__dict__.copy()
-        for k in ("_handle", "_x_dev", "kernel", "solver"):
+        for k in ("_handle", "_x_dev", "kernel", "solver", "_last_grad_buf"):
             st[k] = None
         st["_cap"] = 0
         st["_was_computed"] = self.computed
@@ -423,15 +423,23 @@ class HipGP:
         td = _to_dev(t, 2)
         if td.shape[1] != self.ndim:
             raise ValueError(f"t has {td.shape[1]} columns, GP has ndim={self.ndim}")
-        m = int(td.shape[0])
-        mu = torch.empty(m, dtype=torch.float64, device=td.device)
-        var = torch.empty(m, dtype=torch.float64, device=td.device)
-        dmu = torch.empty((m, self.ndim), dtype=torch.float64, device=td.device)
-        dvar = torch.empty((m, self.ndim), dtype=torch.float64, device=td.device)
+        m, d = int(td.shape[0]), self.ndim
+        buf = torch.empty(m * (2 + 2 * d), dtype=torch.float64, device=td.device)     # ONE allocation: the four results are views of it
+        mu, var = buf[:m], buf[m:2 * m]
+        dmu, dvar = buf[2 * m:2 * m + m * d].view(m, d), buf[2 * m + m * d:].view(m, d)
         st = _lib.lib().alabi_gp_predict_grad(self._handle, _lib.ptr(td), m, _lib.ptr(mu), _lib.ptr(var), _lib.ptr(dmu),
                                               _lib.ptr(dvar), _lib.current_stream())
         _lib.check(st, "alabi_gp_predict_grad")
+        self._last_grad_buf = buf
         return mu, var, dmu, dvar
+
+    def predict_grad_host(self, y, t):
+        """The same as NumPy arrays, brought back with ONE device-to-host copy (the polish step of find_next_point calls this ~30
+        times per active-learning iteration: four separate copies cost more than the kernels)."""
+        mu, var, dmu, dvar = self.predict_grad_device(y, t)
+        m, d = int(mu.shape[0]), self.ndim
+        h = self._last_grad_buf.cpu().numpy()
+        return h[:m], h[m:2 * m], h[2 * m:2 * m + m * d].reshape(m, d), h[2 * m + m * d:].reshape(m, d)
 
     def predict(self, y, t, return_cov=True, return_var=False, cache=True, kernel=None):
         """george GP.predict (core.py:85, :95, :1441, :1601).  return_var wins over return_cov."""

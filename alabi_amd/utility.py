@@ -306,8 +306,8 @@ def polish_point(gp, y, theta0, bounds, algorithm="bape", y_best=0.0, maxiter=30
     x0 = np.clip(np.asarray(theta0, dtype=np.float64).ravel(), box[:, 0], box[:, 1])
 
     def fun(x):
-        mu, var, dmu, dvar = gp.predict_grad_device(y, x.reshape(1, -1))
-        u, g = utility_value_and_grad(algorithm, float(mu[0]), float(var[0]), dmu[0].cpu().numpy(), dvar[0].cpu().numpy(), y_best)
+        mu, var, dmu, dvar = gp.predict_grad_host(y, x.reshape(1, -1))
+        u, g = utility_value_and_grad(algorithm, float(mu[0]), float(var[0]), dmu[0], dvar[0], y_best)
         return (u, g) if np.isfinite(u) else (1e100, np.zeros_like(x))
 
     u0, _ = fun(x0)
