@@ -37,6 +37,7 @@ SIGNATURES = {
     "alabi_gp_set_kernel": (_i, [_vp, _i, _d]),
     "alabi_gp_compute": (_i, [_vp, _vp, _i, _vp]),
     "alabi_gp_last_pivot": (_i, [_vp, _pi]),
+    "alabi_gp_last_factor_path": (_i, [_vp, _pi]),
     "alabi_gp_set_y": (_i, [_vp, _vp, _vp]),
     "alabi_gp_predict": (_i, [_vp, _vp, _ll, _vp, _vp, _vp]),
     "alabi_gp_fit_predict": (_i, [_vp, _vp, _i, _vp, _vp, _ll, _vp, _pd, _vp]),

@@ -187,7 +187,8 @@ int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream) {
     // 16..160 block columns: the task-queue factorisation (one launch); a wait that runs out there is remembered for a while
     static std::atomic<int> tasks_penalty{0};
     int queued = 0, ctl_ints = 0;
-    if (tasks_penalty.load(std::memory_order_relaxed) > 0) tasks_penalty.fetch_sub(1, std::memory_order_relaxed);
+    const char* tq = getenv("ALABI_CHOL_TASKS");              // "1" forces the queue: then the penalty does not apply either
+    if (!(tq && tq[0] == '1') && tasks_penalty.load(std::memory_order_relaxed) > 0) tasks_penalty.fetch_sub(1, std::memory_order_relaxed);
     else if ((st = cholesky_tasks_prepare(gp, s, &ctl_ints)) != ALABI_OK) return st;
     if ((st = launch_assemble(gp, s, ctl_ints)) != ALABI_OK) return st;   // also clears the status word and the queue's control words
     if (ctl_ints > 0 && (st = launch_cholesky_tasks(gp, s, &queued)) != ALABI_OK) return st;
@@ -198,7 +199,9 @@ int alabi_gp_compute(alabi_gp* gp, const double* X, int N, void* stream) {
     ALABI_HIP_CHECK(hipMemcpyAsync(&gp->host_status[0], gp->info, sizeof(int), hipMemcpyDeviceToHost, s));
     if (queued) ALABI_HIP_CHECK(hipMemcpyAsync(&gp->host_status[1], gp->chol_ctl + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     ALABI_HIP_CHECK(hipStreamSynchronize(s));
+    gp->factor_path = queued ? 2 : 1;
     if (queued && gp->host_status[1]) {                     // undefined matrix state: assemble and factorise again, step by step
+        gp->factor_path = 3;
         tasks_penalty.store(64, std::memory_order_relaxed);
         if ((st = launch_assemble(gp, s)) != ALABI_OK) return st;
         if ((st = launch_cholesky(gp, s)) != ALABI_OK) return st;
@@ -359,6 +362,12 @@ int alabi_gp_get_factor(alabi_gp* gp, double* L_out, void* stream) {
     hipLaunchKernelGGL(copy_factor_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, as_stream(stream),
                        gp->L, gp->Npad, gp->N, L_out);
     ALABI_LAUNCH_CHECK();
+    return ALABI_OK;
+}
+
+int alabi_gp_last_factor_path(alabi_gp* gp, int* path) {
+    if (!gp || !path) return ALABI_BAD_ARGUMENT;
+    *path = gp->factor_path;
     return ALABI_OK;
 }
 

@@ -58,6 +58,7 @@ struct alabi_gp {
     bool has_alpha = false;
     long long gen = 0;  // bumped by every compute / set_y / set_hyper
     int last_pivot = 0;
+    int factor_path = 0;      // alabi_gp_last_factor_path
     // hyper-parameters (host copies)
     double mean = 0.0, log_wn = -12.0, log_amp = 0.0;
     alabi::KernelFn kf{0, 1.0};   // kernel family (+ alpha of the rational quadratic)
@@ -185,6 +186,7 @@ struct CholBatchQueue {
     int* list_off = nullptr;                    // device [nlists + 1]
     CholMat* mats = nullptr; size_t mats_cap = 0;
     int* ctl = nullptr; size_t ctl_ints = 0, ctl_cap = 0;   // [32 q] list heads, [1] time-out flag, from [256] on: per matrix tile versions + slab counters
+    double* linv = nullptr; size_t linv_cap = 0;            // per matrix [nb][4][16][16]: inverses of the diagonal 16 x 16 blocks (matrix-core panel solves)
 };
 int chol_batch_prepare(CholBatchQueue& q, int B, const int* ld, double* const* A, double* const* dinv, int* const* info, hipStream_t s);
 int chol_batch_launch(CholBatchQueue& q, hipStream_t s);

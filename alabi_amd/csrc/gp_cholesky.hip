@@ -36,14 +36,15 @@ __device__ inline void tile_update_16(double (*C)[LD], int cr, int cc, double (*
                                       int c0, int lane) {
     const int lr = lane & 15, lk = lane >> 4;
     v4f64 acc;
+    double a[4], b[4];                                      // all twelve LDS reads in flight at once (one round trip, not five)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { a[kk] = Pm[pr + lr][c0 + 4 * kk + lk]; b[kk] = Qm[qr + lr][c0 + 4 * kk + lk]; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = C[cr + lk + 4 * i][cc + lr];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const double a = -Pm[pr + lr][c0 + 4 * kk + lk];
-        const double b = Qm[qr + lr][c0 + 4 * kk + lk];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
+    for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(a[kk]), "+v"(b[kk]));
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[kk], b[kk], acc, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) C[cr + lk + 4 * i][cc + lr] = acc[i];
 }
@@ -533,9 +534,30 @@ syrk_panel_kernel(double* __restrict__ A, int ld, int n, int col0, int kp, int r
 //             4 UPDATE2 = UPDATE(i,j,..) and UPDATE(i+1,j,..) in one task (eight-wave kernel), 5 UPDATE4 = the 2 x 2 block of tiles
 //             (i,j), (i+1,j), (i,j+1), (i+1,j+1), i >= j + 1
 struct CholTask { int type, i, j, k; };
+// Every coherent load / store of the queue names the GLOBAL address space: inside the non-inlined phase functions, and in the batched
+// kernel (whose matrix pointers are loaded from a table), the pointers are generic to the compiler and the accesses became flat_load /
+// flat_store -- the slab stores of the diagonal factorisation took 0.1 us each.
+typedef __attribute__((address_space(1))) unsigned long long* ct_gptr64;
+typedef __attribute__((address_space(1))) int* ct_gptr32;
+__device__ inline ct_gptr64 ct_g64(const double* p) { return (ct_gptr64)(unsigned long long*)const_cast<double*>(p); }
+__device__ inline ct_gptr32 ct_g32(const int* p) { return (ct_gptr32)const_cast<int*>(p); }
+// ... and the tiles, slabs and inverse blocks that are handed on go out in 16-byte pieces: a coherent (write-through) store is one fabric
+// write per lane, and an 8-byte one costs 2.7x the time per byte of a 16-byte one (MI355X_MICROARCH.md).  A 64-row block at `base` with
+// row stride ld as a buffer: (row, column) -> byte offset.
+typedef unsigned int ct_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int ct_u32x2 __attribute__((ext_vector_type(2)));
+__device__ inline __amdgpu_buffer_rsrc_t ct_block_rsrc(double* base, int ld) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (unsigned)(63 * ld + 64) * 8u, 0x00020000);
+}
+// the pair (r, c), (r, c + 1) of a block, c even; lower = only what lies on or below the diagonal of the block
+__device__ inline void ct_store_pair(__amdgpu_buffer_rsrc_t rs, int ld, int r, int c, ct_u32x4 v, bool lower) {
+    const unsigned off = (unsigned)(r * ld + c) * 8u;
+    if (!lower || c + 1 <= r) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
+    else if (c == r) { ct_u32x2 h = {v.x, v.y}; __builtin_amdgcn_raw_buffer_store_b64(h, rs, off, 0, 16); }
+}
 // Batched queue (chol_tasks8_batch_kernel): bits 16.. of `type` say which matrix of the batch the task belongs to; the matrices are
 // independent, each with its own tile versions, slab counters, status word and reciprocal diagonal.
-struct CholMat { double* A; double* dinv; int* ver; int* sver; int* info; int ld, nb; };
+struct CholMat { double* A; double* dinv; double* linv; int* ver; int* sver; int* info; int ld, nb; };
 #define ALABI_CHOL_TASKS_MAX_NB 256   // default upper end of the one-launch task queue (N <= 16384); beyond: panels of 8 block columns
 #define ALABI_CHOL_W8_MIN_NB 16   // block columns from which the queue runs eight waves per workgroup (chol_tasks8_kernel)
 #define ALABI_CHOL_UPDATE4_MIN_NB 100 // block columns from which the far updates take 2 x 2 tiles per task (UPDATE4; below: UPDATE2)
@@ -547,25 +569,34 @@ __device__ inline void tile_load_sc1(double (*T)[66], const double* __restrict__
 #pragma unroll
     for (int e_ = 0; e_ < 4096 / NT; ++e_) {
         const int e = tid + NT * e_, r = e >> 6, c = e & 63;
-        T[r][c] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(src + (size_t)r * ld + c),
+        T[r][c] = __longlong_as_double((long long)__hip_atomic_load(ct_g64(src + (size_t)r * ld + c),
                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
 }
 template <int NT>
 __device__ inline void tile_store_sc1(double* __restrict__ dst, int ld, double (*T)[66], int tid, bool lower_only) {
+    // every LDS read first, unconditionally, then the stores: written as "if (lower) store(T[r][c])" the compiler reads, waits and stores
+    // element by element under the predicate -- 16 LDS round trips in a row
+    const __amdgpu_buffer_rsrc_t rs = ct_block_rsrc(dst, ld);
+    ct_u32x4 v[2048 / NT];
 #pragma unroll
-    for (int e_ = 0; e_ < 4096 / NT; ++e_) {
-        const int e = tid + NT * e_, r = e >> 6, c = e & 63;
-        if (!lower_only || c <= r)
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + (size_t)r * ld + c),
-                               (unsigned long long)__double_as_longlong(T[r][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int e_ = 0; e_ < 2048 / NT; ++e_) {
+        const int e = tid + NT * e_;
+        v[e_] = *reinterpret_cast<const ct_u32x4*>(&T[e >> 5][2 * (e & 31)]);
+    }
+#pragma unroll
+    for (int e_ = 0; e_ < 2048 / NT; ++e_) asm volatile("" : "+v"(v[e_]));
+#pragma unroll
+    for (int e_ = 0; e_ < 2048 / NT; ++e_) {
+        const int e = tid + NT * e_;
+        ct_store_pair(rs, ld, e >> 5, 2 * (e & 31), v[e_], lower_only);
     }
 }
 // every wave has drained its stores and passed the barrier before ONE lane publishes the version
 __device__ inline void publish_version(int* ver, int value, int tid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(ver, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(ct_g32(ver), value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Module-scope LDS, named directly by the non-inlined phase functions (as pointer arguments they would degrade to generic
@@ -576,23 +607,157 @@ __shared__ double ct_pool[8 * 64 * 34];                               // one arr
 #define ct_T1 (reinterpret_cast<double (*)[66]>(ct_pool + 64 * 66))
 #define ct_T2 (reinterpret_cast<double (*)[66]>(ct_pool + 2 * 64 * 66))   // CHAIN: the diagonal tile, parked while the panel tile is solved
 #define ct_T3 (reinterpret_cast<double (*)[66]>(ct_pool + 3 * 64 * 66))   // UPDATE over several block columns: second operand pair (T2, T3)
-__shared__ double ct_di[64];
-// One 16-column slab of the panel solve (CHAIN: the slabs of L[k-1,k-1] arrive one by one, see ct_potrf_publish).
-// The slab's recurrence for all 64 rows of the tile by ONE wave (lane = row; the instruction stream is the same as for 16
-// rows): the other waves are then free to fetch the next slab of L[kk,kk] meanwhile (solve_by_slabs).
-template <int S>
-__device__ __attribute__((noinline)) void ct_trsm_rec() {
-    trsm_slab_row<66>(ct_T0, ct_T1, ct_di, threadIdx.x & 63, 16 * S);
-}
-// The slab's effect on the later slabs: rank-16 updates on the matrix cores, wave w owns rows 16 w .. 16 w + 15.
-template <int S>
-__device__ __attribute__((noinline)) void ct_trsm_upd() {
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    // wave w owns rows 16 (w & 3) ..; with eight waves the helper wave w + 4 takes every second of its column tiles
-    const int half = w >> 2, two = (int)(blockDim.x >> 9);     // two = 1 with eight waves
+__shared__ int ct_task_s[16];                                          // the task loop's words (chol_tasks_body) + [9]: slabs of L[kk,kk] seen by a solve
+#ifdef ALABI_CHOL_LOG
+// Event log of the CHAIN tasks (tools/run_chol_log.sh): 10-ns time stamps written with plain stores by thread 0 -- no read-modify-write on
+// the chain, unlike the ALABI_CHOL_PROF counters.  [k][0] drawn, [1] dependencies met, [2] tiles in LDS, [3..6] slab s of L[k-1,k-1] seen,
+// [7] solve + diagonal update done, [8] panel tile published, [9] factorisation starts, [10..13] slab recurrence s done, [14] last inverse
+// block out, [15] tile stored and published.
+__device__ long long g_chain_log[256][32];   // [16 + 2 s] / [17 + 2 s]: factorisation past barrier A / B of slab s
+__shared__ int ct_log_kb;
+#define CT_LOG(i) do { if (threadIdx.x == 0) g_chain_log[ct_log_kb][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define CT_LOGW(i) do { if ((threadIdx.x & 63) == 0) g_chain_log[ct_log_kb][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CT_LOGW(i) do { } while (0)
+#define CT_LOG(i) do { } while (0)
+#endif
+// Lower-triangle tile j of the 4 x 4 grid of 16 x 16 tiles of a diagonal tile: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) (3,0) .. (3,3)
+__device__ inline void ct_diag_tile(int j, int& rt, int& ct) { rt = j >= 6 ? 3 : j >= 3 ? 2 : j >= 1 ? 1 : 0; ct = j - rt * (rt + 1) / 2; }
+// The slabs [s0, s1) of L[kk,kk] into ct_T0 in ONE memory round trip (a coherent load takes 0.7-1 us, whatever it fetches): of slab q
+// the rows below its diagonal block (L[t,q], t > q: what the solve applies to the later slabs) and, IN PLACE of the diagonal block, its
+// inverse from `linv` ([4][16][16], row-major) -- the solve never reads L[q,q].  One copy of the code: the bounds are run-time values.
+template <int NT>
+__device__ inline void ct_fetch_slabs(const double* __restrict__ Lp, int ld, const double* __restrict__ linv, int tid, int s0, int s1) {
+    constexpr int NE = 1024 / NT;
+    unsigned long long v[3][NE], iv[4];
 #pragma unroll
-    for (int t = S + 1; t < 4; ++t)
-        if ((((t - S - 1) & 1) & two) == half) tile_update_16<66>(ct_T1, 16 * (w & 3), 16 * t, ct_T1, 16 * (w & 3), ct_T0, 16 * t, 16 * S, lane);
+    for (int q = 0; q < 4; ++q) {
+        if (q >= s0 && q < s1) {
+            if (q < 3) {
+#pragma unroll
+                for (int e_ = 0; e_ < NE; ++e_) {
+                    const int e = tid + NT * e_, r = e >> 4, c = 16 * q + (e & 15);
+                    if (r >= 16 * (q + 1))
+                        v[q < 3 ? q : 0][e_] = __hip_atomic_load(ct_g64(Lp + (size_t)r * ld + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (tid < 256) iv[q] = __hip_atomic_load(ct_g64(linv + q * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q >= s0 && q < s1) {
+            if (q < 3) {
+#pragma unroll
+                for (int e_ = 0; e_ < NE; ++e_) {
+                    const int e = tid + NT * e_, r = e >> 4, c = 16 * q + (e & 15);
+                    if (r >= 16 * (q + 1)) ct_T0[r][c] = __longlong_as_double((long long)v[q < 3 ? q : 0][e_]);
+                }
+            }
+            if (tid < 256) ct_T0[16 * q + (tid >> 4)][16 * q + (tid & 15)] = __longlong_as_double((long long)iv[q]);
+        }
+    }
+}
+// Panel solve X L_kk^T = B of the tile in ct_T1 ENTIRELY ON THE MATRIX CORES (round 4; before: a 16-step recurrence per slab in one
+// wave, 1.8 us per slab, 7.2 us per tile -- 30 % of the workgroup time of a batch of N = 1600 matrices and the tail of every CHAIN).
+// The diagonal factorisation publishes, per 16-column slab s, the inverse of the slab's 16 x 16 diagonal block (ct_potrf_publish:
+// wave 1 runs the slab's recurrence on the block's rows and on the rows of the identity beside wave 0, so the inverse costs the
+// chain nothing); with it
+//     X_s = (B_s - sum_{u<s} X_u L_su^T) inv(L_ss)^T.
+// Wave w (< 4) owns rows 16 w .. of the tile and works on the TRANSPOSE, Y = X^T: Y_s = inv(L_ss) (B_s^T - sum_u L_su Y_u).  Then the
+// result of a product (C/D layout: row 4 i + (lane >> 4), column lane & 15) is, register i for k-step i, exactly the B operand of the
+// next one (B[k = lane >> 4][n = lane & 15]), so the four slab steps chain in registers: 4 + 4 (3 - s) matrix-core instructions per slab
+// and wave, 40 per tile = 1.1 us, no cross-lane traffic and no barrier between the slabs.  The slabs of L[kk,kk] are taken as they are
+// published (sver[kk] = slabs available; all that are there in ONE fetch when the tile is final).  Error of a slab: that of a product
+// with the explicit inverse of a 16 x 16 block, eps cond(L_ss) -- the blocks are small, tests hold ||L L^T - K|| <= 1e-12 ||K||.
+// DIAG (CHAIN): tile (k,k), parked in ct_T2, takes - X X^T slab by slab behind the solve (its ten lower 16 x 16 tiles dealt to all
+// waves, accumulators in registers) and ends up in ct_T0 for the factorisation; the solved tile is written to Xdst while the last
+// of that runs.  Returns false when a wait ran out (err set, every thread leaves).
+template <int NT, bool DIAG>
+__device__ __attribute__((noinline)) bool ct_solve(const double* __restrict__ Lp, int ld, const double* __restrict__ linv, int* sver, int* err,
+                                                   int spin_limit, int ntasks, double* __restrict__ Xdst) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+    constexpr int NW = NT / 64, NQ = (10 + NW - 1) / NW;       // lower 16 x 16 tiles of the diagonal tile per wave: 3 (four waves) / 2 (eight)
+    v4f64 Y[4], dacc[NQ];
+    int have = 0;                                              // slabs of L[kk,kk] in ct_T0
+    auto slab = [&](auto s_tag) -> bool {
+        constexpr int S = decltype(s_tag)::value;
+        if (have <= S) {
+            if (tid == 0) {
+                int v, spins = 0;
+                while ((v = __hip_atomic_load(ct_g32(sver), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < S + 1) {
+                    if (++spins > spin_limit || ((spins & 63) == 0 && __hip_atomic_load(ct_g32(err), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        __hip_atomic_store(ct_g32(err), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ct_task_s[4] = ntasks;
+                        v = -1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                ct_task_s[9] = v;
+            }
+            __syncthreads();
+            const int got = ct_task_s[9];
+            if (got < 0) return false;
+            if constexpr (DIAG) { for (int q_ = S; q_ < got && q_ < 4; ++q_) CT_LOG(3 + q_); }
+            have = got < 4 ? got : 4;                          // everything that is there, in one round trip
+            ct_fetch_slabs<NT>(Lp, ld, linv, tid, S, have);
+            __syncthreads();                                   // the slab(s) -- and at S = 0 the caller's tiles -- are in LDS
+        }
+        if (w < 4) {
+            if (S == 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Y[t][i] = ct_T1[16 * w + lr][16 * t + 4 * i + lk];
+            }
+            v4f64 Z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(ct_T0[16 * S + lr][16 * S + 4 * kk + lk], Y[S][kk], Z, 0, 0, 0);
+#pragma unroll
+            for (int t = S + 1; t < 4; ++t)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    Y[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ct_T0[16 * t + lr][16 * S + 4 * kk + lk], Z[kk], Y[t], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ct_T1[16 * w + lr][16 * S + 4 * i + lk] = Z[i];
+        }
+        if constexpr (DIAG) {
+            __syncthreads();                                   // slab S of X is in ct_T1 for all 64 rows (and nobody reads ct_T0's slab S any more)
+            if (S == 3) tile_store_sc1<NT>(Xdst, ld, ct_T1, tid, false);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int j = w + NW * q;
+                if (j < 10) {
+                    int rt, ct;
+                    ct_diag_tile(j, rt, ct);
+                    if (S == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dacc[q][i] = ct_T2[16 * rt + lk + 4 * i][16 * ct + lr];
+                    }
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) {
+                        const int ks = 4 * S + kq;
+                        dacc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ct_T1[16 * rt + lr][4 * ks + lk], ct_T1[16 * ct + lr][4 * ks + lk], dacc[q], 0, 0, 0);
+                    }
+                    if (S == 3) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ct_T0[16 * rt + lk + 4 * i][16 * ct + lr] = dacc[q][i];
+                    }
+                }
+            }
+        }
+        return true;
+    };
+    if (!slab(std::integral_constant<int, 0>{})) return false;
+    if (!slab(std::integral_constant<int, 1>{})) return false;
+    if (!slab(std::integral_constant<int, 2>{})) return false;
+    if (!slab(std::integral_constant<int, 3>{})) return false;
+    if constexpr (!DIAG) {
+        __syncthreads();
+        tile_store_sc1<NT>(Xdst, ld, ct_T1, tid, false);
+    }
+    return true;
 }
 // The diagonal factorisation of CHAIN(k) (potrf_tile_lds_wg on ct_T0) that hands its result on SLAB BY SLAB: the 16 columns
 // of a slab are final for all 64 rows as soon as wave 0 has run the slab's recurrence, and the panel solve of the next chain
@@ -600,20 +765,44 @@ __device__ __attribute__((noinline)) void ct_trsm_upd() {
 // its 16 reciprocals) through to memory and, one barrier later when its stores have drained, publishes sver[k] = slab + 1.
 // The next CHAIN task then solves slab s while this one factorises slab s + 1 .. 3 instead of starting after the whole tile.
 #ifdef ALABI_CHOL_PROF
-__device__ long long g_potrf_prof[2];                          // 10-ns ticks inside wave 0's slab recurrences, slabs
+__device__ long long g_potrf_prof[8];                          // 10-ns ticks inside wave 0's slab recurrences, slabs; [2] start -> barrier A, [3] A -> B, [4] last slab incl. its stores, [5] count
 #endif
+// The inverses of the slabs' 16 x 16 diagonal blocks, which the matrix-core panel solves multiply by (ct_solve), cost the chain nothing:
+//   slabs 1..3: lanes 0..15 of wave 0 -- rows above the slab, idle in its recurrence -- carry the rows of the identity through the SAME
+//     recurrence (x L_ss^T = e_i by forward substitution) and come out as the rows of inv(L_ss)^T; the last block, all the next panel solve
+//     waits for at the end, goes out at once, the others with their slab;
+//   slab 0 (no idle lanes): wave 0 gives up rows 48..63 for the identity, and wave 1 runs the same recurrence beside it for those rows
+//     (lanes 16..31; its lanes 0..15 repeat rows 0..15, the source of the multipliers, bit for bit).
+// The function must stay within the caller-saved registers and call nothing: with a substitution of ~215 live registers inside it (or a
+// call to one) every CHAIN task saved and restored up to 79 registers through scratch memory -- the factorisation took 12-13 us instead of 9.
+// (Also measured and not kept: ONE non-inlined copy of the recurrence for every slab, with the slab offset at run time: 1.52 instead of
+// 1.26 us per slab.)
 __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, double* __restrict__ D, int ld, double* __restrict__ dinv,
-                                                            int* sver) {
+                                                            int* sver, double* __restrict__ linv) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nwm = (int)(blockDim.x >> 6) - 1;               // 3 or 7: the rank-16 tile updates between slabs are dealt to ALL waves of the workgroup
+    double* const inv_s = ct_pool + 3 * 64 * 66;              // T3: inverses of the slabs' diagonal blocks, [slab & 1][n][k]
     kb = __builtin_amdgcn_readfirstlane(kb);
+    if (tid == 0) ct_task_s[10] = 0;                          // (read two barriers from here at the earliest)
+    // owner of the 16 x 16 tile (ti, tk) of the trailing part, tk >= 1: one wave applies every slab to it, in order.  Column 1: waves 0, 1, 2;
+    // columns 2 and 3 (which receive slabs UNDER a recurrence of wave 0): waves 4, 5, 6 with eight waves, 1, 2, 1 with four
+    auto owner = [nwm](int ti, int tk) { return tk == 1 ? ti - 1 : nwm == 7 ? (tk == 2 ? ti + 2 : 6) : (tk == 2 ? ti - 1 : 1); };
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int c0 = 16 * s;
+#ifdef ALABI_CHOL_PROF
+        const long long pq_ = __builtin_amdgcn_s_memrealtime();
+#endif
         if (w == 0) {
             double a[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) a[j] = ct_T0[lane][c0 + j];
+            {                                                  // rows of the identity: lanes 0..15 (slab 0: lanes 48..63, wave 1 has those rows)
+                const int il = s > 0 ? lane : lane - 48;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a[j] = (il >= 0 && il < 16) ? (j == il ? 1.0 : 0.0) : a[j];
+            }
+            if (s == 0) __syncthreads();                       // wave 1 has read rows 0..15 before this wave writes them back
 #ifdef ALABI_CHOL_PROF
             long long q0_, q1_;
             {   // stamps that depend on the data: after the slab is in registers / after its last entry is final
@@ -630,36 +819,121 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
             }
             if (lane == 0) { g_potrf_prof[0] += q1_ - q0_; g_potrf_prof[1] += 1; }
 #endif
+            CT_LOG(10 + s);
+            if (s > 0 ? lane < 16 : lane >= 48) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) ct_T0[lane][c0 + j] = a[j];
-        } else if (w == 3 && s > 0) {                          // slab s - 1 was written out in the previous round: publish it
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(sver, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int j = 0; j < 16; ++j) inv_s[256 * (s & 1) + j * 16 + (lane & 15)] = a[j];   // identity lane i holds row i of inv(L_ss)^T
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ct_T0[lane][c0 + j] = a[j];
+            }
+            if (s == 3) {                                      // (LDS operations of one wave are executed in order)
+                const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(linv, 0, 8192u, 0x00020000);
+                ct_u32x4 iv[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) iv[q] = *reinterpret_cast<const ct_u32x4*>(&inv_s[256 + 2 * (lane + 64 * q)]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(iv[q]));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) __builtin_amdgcn_raw_buffer_store_b128(iv[q], rl, (unsigned)(3 * 256 + 2 * (lane + 64 * q)) * 8u, 0, 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                CT_LOG(14);
+            }
+        } else if (w == 1 && s == 0) {                         // rows 48..63 of slab 0 (lanes 16..31) behind a copy of rows 0..15 (lanes 0..15)
+            double a[16];
+            const int row = (lane & 16) ? 48 + (lane & 15) : (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = ct_T0[row][j];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(a[j]));   // (the loads have landed)
+            __syncthreads();
+            potrf_slab(a, 0);
+            if (lane >= 16 && lane < 32) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ct_T0[row][j] = a[j];
+            }
+        } else if (s == 0) {
+            __syncthreads();                                   // (the barrier between wave 1's reads and wave 0's writes, see above)
+        } else {
+            // the storing waves (below): their halves of slab s - 1 have drained -> wave 3 publishes the slab
+            if (w == 7) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) *(volatile __attribute__((address_space(3))) int*)&ct_task_s[10] = s;
+            } else if (w == 3) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (nwm == 7) while (*(volatile __attribute__((address_space(3))) int*)&ct_task_s[10] < s) __builtin_amdgcn_s_sleep(1);
+                if (lane == 0) __hip_atomic_store(ct_g32(sver), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (s == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // in front of the "4" below
+            }
+            // the rest of slab s - 1's rank-16 update -- the tiles right of tile column s, which the coming recurrence neither reads nor
+            // writes -- under that recurrence, each tile by its owner (who applied the earlier slabs to it and will apply the next)
+#pragma unroll
+            for (int tk = s + 1; tk < 4; ++tk)
+#pragma unroll
+                for (int ti = tk; ti < 4; ++ti)
+                    if (owner(ti, tk) == w) tile_update_16<66>(ct_T0, 16 * ti, 16 * tk, ct_T0, 16 * ti, ct_T0, 16 * tk, c0 - 16, lane);
         }
+#ifdef ALABI_CHOL_PROF
+        if (s == 3 && tid == 0) { g_potrf_prof[4] += __builtin_amdgcn_s_memrealtime() - pq_; g_potrf_prof[5] += 1; }
+#endif
         if (s == 3) break;
         __syncthreads();
-        if (w == 3) {                                          // rows c0.., columns c0..c0+15 (lower part), 4 rows x 128 B per store
+        CT_LOG(16 + 2 * s);
+#ifdef ALABI_CHOL_PROF
+        const long long pa_ = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) g_potrf_prof[2] += pa_ - pq_;
+#endif
+        // The slab goes out: rows c0.., its columns (lower part), the inverse of its diagonal block and its reciprocals -- by wave 3, with eight
+        // waves by waves 3 and 7 in halves, in 16-byte pieces.  Write-through stores leave a CU at ~9 GB/s however many waves issue them and
+        // the issuing wave stalls meanwhile, so the 7 KB of slab 0 hold these two waves -- and, at the barrier below, everyone -- for 0.8 us
+        // (measured and not kept: four storing waves on four SIMDs, no faster; the stores UNDER the next recurrence instead, published
+        // when drained: the factorisation 9.9 -> 9.4 us, but every panel solve that waits for the slab waits 1.3 us longer -- a single
+        // matrix of N = 2000 the same 0.50 ms, 500 matrices of N = 1600 26.6 instead of 23.4 ms).
+        if (w == 3 || w == 7) {
+            const __amdgpu_buffer_rsrc_t rs = ct_block_rsrc(D, ld);
+            ct_u32x4 v[8], iv[2];                              // every LDS read first (see tile_store_sc1); rows >= c0: p_ >= 2 s
+            double dl = 1.0;
 #pragma unroll
-            for (int e_ = 0; e_ < 16; ++e_) {
-                const int e = lane + 64 * e_, r = e >> 4, c = c0 + (e & 15);
-                if (c <= r)
-                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(D + (size_t)r * ld + c),
-                                       (unsigned long long)__double_as_longlong(ct_T0[r][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int p_ = 2 * s; p_ < 8; ++p_) {
+                const int e = lane + 64 * p_;
+                v[p_] = *reinterpret_cast<const ct_u32x4*>(&ct_T0[e >> 3][c0 + 2 * (e & 7)]);
             }
-            if (lane < 16)
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(dinv + kb * 64 + c0 + lane),
-                                   (unsigned long long)__double_as_longlong(potrf_dinv(ct_T0[c0 + lane][c0 + lane])), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (w == 3) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) iv[q] = *reinterpret_cast<const ct_u32x4*>(&inv_s[256 * (s & 1) + 2 * (lane + 64 * q)]);
+                dl = ct_T0[c0 + (lane & 15)][c0 + (lane & 15)];
+            }
+#pragma unroll
+            for (int p_ = 2 * s; p_ < 8; ++p_) asm volatile("" : "+v"(v[p_]));
+#pragma unroll
+            for (int p_ = 2 * s; p_ < 8; ++p_) {
+                const int e = lane + 64 * p_;
+                if (nwm != 7 || (p_ & 1) == (w >> 2)) ct_store_pair(rs, ld, e >> 3, c0 + 2 * (e & 7), v[p_], true);
+            }
+            if (w == 3) {
+                const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(linv, 0, 8192u, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) __builtin_amdgcn_raw_buffer_store_b128(iv[q], rl, (unsigned)(s * 256 + 2 * (lane + 64 * q)) * 8u, 0, 16);
+                if (lane < 16)
+                    __hip_atomic_store(ct_g64(dinv + kb * 64 + c0 + lane), (unsigned long long)__double_as_longlong(potrf_dinv(dl)),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        int t = 0;
+        // the slab's rank-16 update of tile column s + 1 -- all the next recurrence needs (one tile per wave: 0.5 us; the whole trailing
+        // part, six tiles at s = 0, took 1.1 us between these barriers); the other tiles follow under that recurrence, above
 #pragma unroll
         for (int ti = s + 1; ti < 4; ++ti)
-#pragma unroll
-            for (int tk = s + 1; tk <= ti; ++tk, ++t)
-                if ((t & nwm) == w) tile_update_16<66>(ct_T0, 16 * ti, 16 * tk, ct_T0, 16 * ti, ct_T0, 16 * tk, c0, lane);
+            if (owner(ti, s + 1) == w) { tile_update_16<66>(ct_T0, 16 * ti, 16 * (s + 1), ct_T0, 16 * ti, ct_T0, 16 * (s + 1), c0, lane); if (ti == s + 1) CT_LOGW(28 + s); }
         __syncthreads();
+        CT_LOG(17 + 2 * s);
+#ifdef ALABI_CHOL_PROF
+        if (tid == 0) g_potrf_prof[3] += __builtin_amdgcn_s_memrealtime() - pa_;
+#endif
     }
     __syncthreads();
+    // every slab and every inverse block is out (wave 3 drained slab 2 before it published it, wave 0 block 3 above): the panel solves
+    // need nothing else of this tile -- not the last diagonal block, which goes out with the whole tile behind this
+    if (tid == 0) __hip_atomic_store(ct_g32(sver), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (w != 0) return 1.0;
     const double lll = ct_T0[lane][lane];
     const int bad = potrf_first_bad(lll);
@@ -674,7 +948,7 @@ __device__ inline void tile_fetch(TileRegs<NT>& r, const double* __restrict__ sr
 #pragma unroll
     for (int e_ = 0; e_ < 4096 / NT; ++e_) {
         const int e = tid + NT * e_;
-        r.v[e_] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src + (size_t)(e >> 6) * ld + (e & 63)), __ATOMIC_RELAXED,
+        r.v[e_] = __hip_atomic_load(ct_g64(src + (size_t)(e >> 6) * ld + (e & 63)), __ATOMIC_RELAXED,
                                     __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -738,12 +1012,13 @@ template <int NT, bool BATCH>
 __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_, int nb_, const CholTask* __restrict__ tasks, int ntasks,
                                                 int* __restrict__ ctl, int* __restrict__ info_, double* __restrict__ dinv_, int spin_limit,
                                                 const CholMat* __restrict__ mats, const int* __restrict__ list_off, int nlists) {
-    double (*T0)[66] = ct_T0; double (*T1)[66] = ct_T1; double (*T2)[66] = ct_T2; double (*T3)[66] = ct_T3; double* di = ct_di;
-    __shared__ int task_s[10];
+    double (*T0)[66] = ct_T0; double (*T1)[66] = ct_T1; double (*T2)[66] = ct_T2; double (*T3)[66] = ct_T3;
+    int (&task_s)[16] = ct_task_s;
     // per task in a batch, fixed otherwise
     double* A = A_; int ld = ld_, nb = nb_; int* info = info_; double* dinv = dinv_;
     int* head = ctl; int* err = ctl + 1; int* ver = ctl + 2;          // ver[i * nb + j]
     int* sver = ctl + 2 + nb * nb;                                    // sver[k]: slabs of L[k,k] published so far (0..4)
+    double* linv = BATCH ? nullptr : reinterpret_cast<double*>(ctl + ((2 + nb * nb + nb + 130 + 1) & ~1));   // [nb][4][16][16]: inverses of the diagonal 16 x 16 blocks
     int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
     __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(A, 0, (unsigned)ld * (unsigned)ld * 8u, 0x00020000);
     if constexpr (BATCH) {
@@ -754,92 +1029,6 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
             task_s[7] = 0;
         }
     }
-    // Panel solve of the tile in T1 against L[kk,kk], consumed slab by slab as its factorisation publishes them (sver[kk] =
-    // slabs written through so far): wait (bounded), fetch the slab's 64 x 16 block and its reciprocals, solve the slab,
-    // update the later slabs on the matrix cores.  false = a wait ran out (err is set; every thread returns).
-    auto solve_by_slabs = [&](int kk, auto&& side) -> bool {   // side(s): run by waves 2 and 3 under the recurrence of slab s + 1, when slab s of the solved tile is final
-        const double* Lp = A + (size_t)(kk * 64) * ld + kk * 64;
-        // slab 0: wait for it (bounded), every thread fetches its share
-        if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(sver + kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 1) {
-                if (++spins > spin_limit || ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    task_s[4] = ntasks;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        __syncthreads();
-        if (task_s[4] >= ntasks) return false;
-        {
-            unsigned long long v[1024 / NT];
-#pragma unroll
-            for (int e_ = 0; e_ < 1024 / NT; ++e_) {
-                const int e = tid + NT * e_;
-                v[e_] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(Lp + (size_t)(e >> 4) * ld + (e & 15)), __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (tid < 16) di[tid] = __longlong_as_double((long long)__hip_atomic_load(
-                              reinterpret_cast<const unsigned long long*>(dinv + kk * 64 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#pragma unroll
-            for (int e_ = 0; e_ < 1024 / NT; ++e_) {
-                const int e = tid + NT * e_;
-                T0[e >> 4][e & 15] = __longlong_as_double((long long)v[e_]);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) {
-            // wave 0 runs the slab's recurrence for all 64 rows; wave 1 meanwhile waits for the NEXT slab of L[kk,kk] and fetches
-            // it (its columns of T0 and its reciprocals have no reader yet): the two memory round trips per slab leave the chain
-            if (w == 0) {
-                if (sl == 0) ct_trsm_rec<0>();
-                else if (sl == 1) ct_trsm_rec<1>();
-                else if (sl == 2) ct_trsm_rec<2>();
-                else ct_trsm_rec<3>();
-            } else if (w == 1 && sl < 3) {
-                const int l1 = tid & 63;
-                int ok = 1, spins = 0;
-                while (__hip_atomic_load(sver + kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sl + 2) {      // wave-uniform
-                    if (++spins > spin_limit || ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        ok = 0;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (!ok) {
-                    if (l1 == 0) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); task_s[4] = ntasks; }
-                } else {
-                    unsigned long long v[16];
-#pragma unroll
-                    for (int e_ = 0; e_ < 16; ++e_) {
-                        const int e = l1 + 64 * e_;
-                        v[e_] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(Lp + (size_t)(e >> 4) * ld + 16 * (sl + 1) + (e & 15)),
-                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (l1 < 16) di[16 * (sl + 1) + l1] = __longlong_as_double((long long)__hip_atomic_load(
-                                     reinterpret_cast<const unsigned long long*>(dinv + kk * 64 + 16 * (sl + 1) + l1), __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT));
-#pragma unroll
-                    for (int e_ = 0; e_ < 16; ++e_) {
-                        const int e = l1 + 64 * e_;
-                        T0[e >> 4][16 * (sl + 1) + (e & 15)] = __longlong_as_double((long long)v[e_]);
-                    }
-                }
-            } else if ((w == 2 || w == 3) && sl >= 1) {
-                side(sl - 1);
-            }
-            __syncthreads();                                          // the slab is solved, the next one is in LDS
-            if (task_s[4] >= ntasks) return false;
-            if (sl == 0) ct_trsm_upd<0>();
-            else if (sl == 1) ct_trsm_upd<1>();
-            else if (sl == 2) ct_trsm_upd<2>();
-            if (sl < 3) __syncthreads();                              // the later slabs carry this slab's update
-        }
-        return true;
-    };
     // (Measured and not kept, round 3: CHAIN(k) applying block column k-2 to its panel tile itself instead of waiting for the
     // one-column UPDATE(k,k-1,k-2) task -- N = 2000 0.55 -> 0.58 ms with four waves, 0.54 -> 0.55 with eight: the period of the
     // chain is set by the 64-pivot factorisation handing its slabs to the next panel solve, not by that task.)
@@ -878,10 +1067,13 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
         __syncthreads();
         if (task_s[4] >= ntasks) return;
         const int type = task_s[0], ti = task_s[1], tj = task_s[2], tk = task_s[3];
+#ifdef ALABI_CHOL_LOG
+        const long long log_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
         const int tcnt = task_s[5] > 0 ? task_s[5] : 1;                 // UPDATE: block columns tk .. tk + tcnt - 1
         if constexpr (BATCH) {                                        // this task's matrix (wave-uniform: scalar loads)
             const CholMat cm = mats[__builtin_amdgcn_readfirstlane(task_s[8])];
-            A = cm.A; ld = cm.ld; nb = cm.nb; ver = cm.ver; sver = cm.sver; info = cm.info; dinv = cm.dinv;
+            A = cm.A; ld = cm.ld; nb = cm.nb; ver = cm.ver; sver = cm.sver; info = cm.info; dinv = cm.dinv; linv = cm.linv;
             arsrc = __builtin_amdgcn_make_buffer_rsrc(A, 0, (unsigned)ld * (unsigned)ld * 8u, 0x00020000);
         }
 #ifdef ALABI_CHOL_PROF
@@ -917,15 +1109,15 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
             int spins = 0, ok = 1;
             while (true) {
                 int have = need;
-                if (active) have = __hip_atomic_load(ver + di_ * nb + dj_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (active) have = __hip_atomic_load(ct_g32(ver + di_ * nb + dj_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all(have >= need)) break;
-                if (++spins > spin_limit || ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if (++spins > spin_limit || ((spins & 63) == 0 && __hip_atomic_load(ct_g32(err), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                     ok = 0;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (!ok && l == 0) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); task_s[4] = ntasks; }
+            if (!ok && l == 0) { __hip_atomic_store(ct_g32(err), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); task_s[4] = ntasks; }
             // an UPDATE over a whole group of block columns streams its operand tiles with ordinary loads (they can hit in the XCD's
             // L2, where the neighbouring tasks of the same tile column have just put them; write-through-coherent loads always go
             // out to the fabric, and the bulk updates are bound by exactly that traffic): one acquire per task makes that valid
@@ -964,7 +1156,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
     #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         acc[n][i] = __longlong_as_double((long long)__hip_atomic_load(
-                            reinterpret_cast<const unsigned long long*>(C + (size_t)(lk + 4 * i) * ld + 16 * n + lr), __ATOMIC_RELAXED,
+                            ct_g64(C + (size_t)(lk + 4 * i) * ld + 16 * n + lr), __ATOMIC_RELAXED,
                             __HIP_MEMORY_SCOPE_AGENT));
                 tile_put16<NT>(T0, ra, tid); tile_put16<NT>(T1, rb, tid);
                 // Column k' + 1 waits in LDS and column k' + 2 is in flight while the matrix cores work on column k': the registers of
@@ -1047,7 +1239,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
                 for (int n = 0; n < NN; ++n)
     #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(C + (size_t)(lk + 4 * i) * ld + 16 * n + lr),
+                        __hip_atomic_store(ct_g64(C + (size_t)(lk + 4 * i) * ld + 16 * n + lr),
                                            (unsigned long long)__double_as_longlong(acc[n][i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
             if (tcnt >= ALABI_CHOL_PLAIN_MIN) update_range(std::true_type{}); else update_range(std::false_type{});
@@ -1096,7 +1288,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             acc[ri][n][i] = __longlong_as_double((long long)__hip_atomic_load(
-                                reinterpret_cast<const unsigned long long*>(C + (size_t)(16 * ri + lk + 4 * i) * ld + 16 * n + lr), __ATOMIC_RELAXED,
+                                ct_g64(C + (size_t)(16 * ri + lk + 4 * i) * ld + 16 * n + lr), __ATOMIC_RELAXED,
                                 __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
                 for (int p = 0; p < 8; ++p) to_lds(p, 0);
@@ -1155,13 +1347,13 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
                     for (int n = 0; n < 4; ++n)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            __hip_atomic_store(reinterpret_cast<unsigned long long*>(C + (size_t)(16 * ri + lk + 4 * i) * ld + 16 * n + lr),
+                            __hip_atomic_store(ct_g64(C + (size_t)(16 * ri + lk + 4 * i) * ld + 16 * n + lr),
                                                (unsigned long long)__double_as_longlong(acc[ri][n][i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid < 4)
-                __hip_atomic_store(ver + (ti + (tid & 1)) * nb + tj + (tid >> 1), tk + tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ct_g32(ver + (ti + (tid & 1)) * nb + tj + (tid >> 1)), tk + tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (type == 4) {
             // ---------------- UPDATE2(i, j, k .. k + tcnt - 1): the grouped update of tiles (i, j) AND (i + 1, j) in one task (eight-wave
             // kernel only).  A 128 x 64 output: wave w owns rows 32 (w & 3) .., columns 32 (w >> 2) .. (2 x 2 accumulator tiles: two A
@@ -1197,7 +1389,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             acc[ri][n][i] = __longlong_as_double((long long)__hip_atomic_load(
-                                reinterpret_cast<const unsigned long long*>(C + (size_t)(16 * ri + lk + 4 * i) * ld + 16 * n + lr), __ATOMIC_RELAXED,
+                                ct_g64(C + (size_t)(16 * ri + lk + 4 * i) * ld + 16 * n + lr), __ATOMIC_RELAXED,
                                 __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
                 for (int p = 0; p < 6; ++p) to_lds(p, 0);
@@ -1255,14 +1447,14 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
                     for (int n = 0; n < 2; ++n)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            __hip_atomic_store(reinterpret_cast<unsigned long long*>(C + (size_t)(16 * ri + lk + 4 * i) * ld + 16 * n + lr),
+                            __hip_atomic_store(ct_g64(C + (size_t)(16 * ri + lk + 4 * i) * ld + 16 * n + lr),
                                                (unsigned long long)__double_as_longlong(acc[ri][n][i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                __hip_atomic_store(ver + ti * nb + tj, tk + tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ver + (ti + 1) * nb + tj, tk + tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ct_g32(ver + ti * nb + tj), tk + tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ct_g32(ver + (ti + 1) * nb + tj), tk + tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else if (type == 1) {
             // ---------------- TRSM(i, k)
@@ -1271,12 +1463,16 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
                 tile_fetch<NT>(rb, A + (size_t)(ti * 64) * ld + tk * 64, ld, tid);
                 tile_put<NT>(T1, rb, tid);
             }
-            if (!solve_by_slabs(tk, [](int) {})) return;
-            tile_store_sc1<NT>(A + (size_t)(ti * 64) * ld + tk * 64, ld, T1, tid, false);
+            if (!ct_solve<NT, false>(A + (size_t)(tk * 64) * ld + tk * 64, ld, linv + (size_t)tk * 1024, sver + tk, err, spin_limit, ntasks,
+                                     A + (size_t)(ti * 64) * ld + tk * 64)) return;
             publish_version(ver + ti * nb + tk, tk + 1, tid);
         } else {
             // ---------------- CHAIN(k)
             double* D = A + (size_t)(tk * 64) * ld + tk * 64;
+#ifdef ALABI_CHOL_LOG
+            if (tid == 0) { ct_log_kb = tk; g_chain_log[tk][0] = log_t0; g_chain_log[tk][1] = __builtin_amdgcn_s_memrealtime(); }
+            __syncthreads();
+#endif
 #ifdef ALABI_CHOL_PROF
             long long* prof = reinterpret_cast<long long*>(ctl + ((2 + nb * nb + nb + 1) & ~1));
             const long long p0 = __builtin_amdgcn_s_memrealtime();
@@ -1292,52 +1488,20 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
 #ifdef ALABI_CHOL_PROF
                 p1 = __builtin_amdgcn_s_memrealtime();
 #endif
-                // tile (k,k) -= X X^T (lower triangle: ten 16 x 16 tiles) is accumulated by waves 2 and 3 -- idle while wave 0 runs a
-                // slab's recurrence and wave 1 fetches the next slab -- one solved slab of X behind the solve; only the last slab's
-                // share follows it.   w2: (0,0) (1,0) (1,1) (2,0) (2,1)    w3: (2,2) (3,0) (3,1) (3,2) (3,3)
-                v4f64 dacc[5];
-                auto dtile = [&](int j, int& rt, int& ct) {
-                    if (w == 2) { rt = j == 0 ? 0 : j < 3 ? 1 : 2; ct = j == 0 ? 0 : j == 1 ? 0 : j == 2 ? 1 : j == 3 ? 0 : 1; }
-                    else { rt = j == 0 ? 2 : 3; ct = j == 0 ? 2 : j - 1; }
-                };
-                auto diag_update = [&](int sl) {
-                    if (sl == 0) {
-#pragma unroll
-                        for (int j = 0; j < 5; ++j) {
-                            int rt, ct; dtile(j, rt, ct);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) dacc[j][i] = T2[16 * rt + lk + 4 * i][16 * ct + lr];
-                        }
-                    }
-#pragma unroll
-                    for (int kq = 0; kq < 4; ++kq) {
-                        const int ks = 4 * sl + kq;
-#pragma unroll
-                        for (int j = 0; j < 5; ++j) {
-                            int rt, ct; dtile(j, rt, ct);
-                            dacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-T1[16 * rt + lr][4 * ks + lk], T1[16 * ct + lr][4 * ks + lk], dacc[j], 0, 0, 0);
-                        }
-                    }
-                };
-                // the panel solve, slab by slab as CHAIN(k-1) publishes the slabs of L[k-1,k-1] (bounded wait each)
-                if (!solve_by_slabs(tk - 1, diag_update)) return;
+                CT_LOG(2);
+                // the panel solve on the matrix cores, slab by slab as CHAIN(k-1) publishes the slabs of L[k-1,k-1] and the inverses of their
+                // diagonal blocks (bounded wait each); tile (k,k) -= X X^T follows it one slab behind and ends up in T0 (ct_solve)
+                if (!ct_solve<NT, true>(A + (size_t)((tk - 1) * 64) * ld + (tk - 1) * 64, ld, linv + (size_t)(tk - 1) * 1024, sver + tk - 1, err,
+                                        spin_limit, ntasks, A + (size_t)(tk * 64) * ld + (tk - 1) * 64)) return;
 #ifdef ALABI_CHOL_PROF
                 p2 = __builtin_amdgcn_s_memrealtime();
 #endif
-                tile_store_sc1<NT>(A + (size_t)(tk * 64) * ld + (tk - 1) * 64, ld, T1, tid, false);
-                if (w == 2 || w == 3) diag_update(3);                              // while the stores drain
+                CT_LOG(7);
                 publish_version(ver + tk * nb + (tk - 1), tk, tid);      // the solved panel tile is final: updates of column k can start
+                CT_LOG(8);
 #ifdef ALABI_CHOL_PROF
                 p3 = __builtin_amdgcn_s_memrealtime();
 #endif
-                if (w == 2 || w == 3) {                                  // (the barrier inside publish_version: everyone is done with T0)
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) {
-                        int rt, ct; dtile(j, rt, ct);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) T0[16 * rt + lk + 4 * i][16 * ct + lr] = dacc[j][i];
-                    }
-                }
             } else {
                 tile_load_sc1<NT>(T0, D, ld, tid);
             }
@@ -1345,19 +1509,21 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
 #ifdef ALABI_CHOL_PROF
             p4 = __builtin_amdgcn_s_memrealtime();
 #endif
-            const double rinv = ct_potrf_publish(tk, info, D, ld, dinv, sver + tk);
+            CT_LOG(9);
+            const double rinv = ct_potrf_publish(tk, info, D, ld, dinv, sver + tk, linv + (size_t)tk * 1024);
 #ifdef ALABI_CHOL_PROF
             const long long p5 = __builtin_amdgcn_s_memrealtime();
 #endif
-            if (w == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dinv + tk * 64 + l),
+            if (w == 0) __hip_atomic_store(ct_g64(dinv + tk * 64 + l),
                                            (unsigned long long)__double_as_longlong(rinv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             tile_store_sc1<NT>(D, ld, T0, tid, true);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                __hip_atomic_store(sver + tk, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ver + tk * nb + tk, tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ct_g32(sver + tk), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ct_g32(ver + tk * nb + tk), tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            CT_LOG(15);
 #ifdef ALABI_CHOL_PROF
             if (tid == 0 && tk > 0) {   // 10-ns units: [0] loads [1] trsm [2] store+publish panel [3] mfma+park [4] potrf [5] store+publish diag [6] count [7] wait for deps
                 const long long p6 = __builtin_amdgcn_s_memrealtime();
@@ -1559,12 +1725,14 @@ int cholesky_tasks_prepare(alabi_gp* gp, hipStream_t s, int* ctl_ints_out) {
     const bool forced_on = env && env[0] == '1', forced_off = env && env[0] == '0';
     if (nb < 3 || nb > 256 || forced_off || (!forced_on && (nb < 16 || nb > ALABI_CHOL_TASKS_MAX_NB))) return ALABI_OK;
     const size_t ctl_ints = 2 + (size_t)nb * nb + nb + 130;            // + 130: alignment + phase timers of an ALABI_CHOL_PROF build
-    if (gp->chol_ctl_ints < ctl_ints) {
+    // behind the control words (8-byte aligned, never cleared): the inverses of the diagonal 16 x 16 blocks, [nb][4][16][16] doubles
+    auto total_ints = [](size_t b) { return ((2 + b * b + b + 130 + 1) & ~(size_t)1) + b * 2048; };
+    if (gp->chol_ctl_ints < total_ints(nb)) {
         if (gp->chol_ctl) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); ALABI_HIP_CHECK(hipFree(gp->chol_ctl)); gp->chol_ctl = nullptr; }
         const size_t cap_nb = gp->n_cap / 64 < 256 ? gp->n_cap / 64 : 256;
-        const size_t cap = 2 + 130 + cap_nb * cap_nb + cap_nb;
-        ALABI_HIP_CHECK(hipMalloc(&gp->chol_ctl, (cap > ctl_ints ? cap : ctl_ints) * sizeof(int)));
-        gp->chol_ctl_ints = cap > ctl_ints ? cap : ctl_ints;
+        const size_t cap = total_ints(cap_nb), need = total_ints(nb);
+        ALABI_HIP_CHECK(hipMalloc(&gp->chol_ctl, (cap > need ? cap : need) * sizeof(int)));
+        gp->chol_ctl_ints = cap > need ? cap : need;
     }
     *ctl_ints_out = (int)ctl_ints;
     return ALABI_OK;
@@ -1601,16 +1769,46 @@ int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
                         q == 8 ? "grouped" : "single-column", 0.01 * h[q] / h[q + 4], 0.01 * h[q + 1] / h[q + 4], 0.01 * h[q + 2] / h[q + 4],
                         0.01 * h[q + 2] / (h[q + 5] ? h[q + 5] : 1), 0.01 * h[q + 3] / h[q + 4], h[q + 4], (double)h[q + 5] / h[q + 4]);
         {
-            long long pp[2] = {0, 0};
+            long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             (void)hipMemcpyFromSymbol(pp, HIP_SYMBOL(g_potrf_prof), sizeof(pp));
             if (pp[1] > 0) fprintf(stderr, "[chol_tasks_kernel] slab recurrence of the diagonal factorisation (wave 0): %.2f us per 16 pivots (n=%lld)\n", 0.01 * pp[0] / pp[1], pp[1]);
-            long long z[2] = {0, 0};
+            if (pp[5] > 0) fprintf(stderr, "[chol_tasks_kernel] per factorisation (us): slabs 0-2 start -> barrier A %.2f each, A -> B %.2f each, last slab incl. its stores %.2f (n=%lld)\n",
+                                   0.01 * pp[2] / (3 * pp[5]), 0.01 * pp[3] / (3 * pp[5]), 0.01 * pp[4] / pp[5], pp[5]);
+            long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_potrf_prof), z, sizeof(z));
         }
         if (h[6] > 0)
             fprintf(stderr, "[chol_tasks_kernel] per CHAIN (us): wait %.2f loads %.2f trsm %.2f store+publish %.2f mfma %.2f potrf %.2f store+publish %.2f (n=%lld)\n",
                     0.01 * h[7] / h[6], 0.01 * h[0] / h[6], 0.01 * h[1] / h[6], 0.01 * h[2] / h[6], 0.01 * h[3] / h[6], 0.01 * h[4] / h[6],
                     0.01 * h[5] / h[6], h[6]);
+    }
+#endif
+#ifdef ALABI_CHOL_LOG
+    if (getenv("ALABI_CHOL_LOG_PRINT")) {
+        static long long h[256][32];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_chain_log), sizeof(h));
+        const char* name[15] = {"drawn -> deps met", "deps met -> tiles in LDS", "tiles in LDS -> slab 0 seen", "slab 0 -> slab 1 seen", "slab 1 -> slab 2 seen",
+                                "slab 2 -> slab 3 seen", "slab 3 seen -> solve + diag update done", "-> panel tile published", "-> factorisation starts",
+                                "-> recurrence 0 done", "-> recurrence 1 done", "-> recurrence 2 done", "-> recurrence 3 done", "-> last inverse block out",
+                                "-> tile stored, published"};
+        const int k0 = nb / 4, k1 = nb - 2;
+        fprintf(stderr, "[chain log] nb = %d, means over CHAIN(%d..%d), us:\n", nb, k0, k1);
+        for (int i = 0; i < 15; ++i) {
+            double sum = 0;
+            for (int k = k0; k <= k1; ++k) sum += 0.01 * (double)(h[k][i + 1] - h[k][i]);
+            fprintf(stderr, "  %-44s %7.2f\n", name[i], sum / (k1 - k0 + 1));
+        }
+        for (int sl = 0; sl < 3; ++sl) {
+            double r2a = 0, a2b = 0, b2r = 0;
+            for (int k = k0; k <= k1; ++k) { r2a += 0.01 * (double)(h[k][16 + 2 * sl] - h[k][10 + sl]); a2b += 0.01 * (double)(h[k][17 + 2 * sl] - h[k][16 + 2 * sl]); b2r += 0.01 * (double)(h[k][11 + sl] - h[k][17 + 2 * sl]); }
+            double wt = 0;
+            for (int k = k0; k <= k1; ++k) wt += 0.01 * (double)(h[k][28 + sl] - h[k][16 + 2 * sl]);
+            fprintf(stderr, "  slab %d: recurrence done -> past barrier A %.2f, A -> B (stores, tile updates) %.2f (diagonal tile updated after %.2f), B -> next recurrence done %.2f\n", sl, r2a / (k1 - k0 + 1), a2b / (k1 - k0 + 1), wt / (k1 - k0 + 1), b2r / (k1 - k0 + 1));
+        }
+        double per = 0, hop = 0;
+        for (int k = k0; k <= k1; ++k) { per += 0.01 * (double)(h[k + 1][9] - h[k][9]); hop += 0.01 * (double)(h[k + 1][6] - h[k][14]); }
+        fprintf(stderr, "  period (factorisation start to start) %.2f; last inverse block out -> seen by the next CHAIN %.2f\n", per / (k1 - k0 + 1), hop / (k1 - k0 + 1));
     }
 #endif
     *launched = 1;
@@ -1816,6 +2014,7 @@ void chol_batch_free(CholBatchQueue& q) {
     if (q.list_off) (void)hipFree(q.list_off);
     if (q.mats) (void)hipFree(q.mats);
     if (q.ctl) (void)hipFree(q.ctl);
+    if (q.linv) (void)hipFree(q.linv);
     q = CholBatchQueue{};
 }
 
@@ -1869,12 +2068,21 @@ int chol_batch_prepare(CholBatchQueue& q, int B, const int* ld, double* const* A
         q.ctl_cap = ctl_ints;
     }
     q.ctl_ints = ctl_ints;
+    size_t linv_doubles = 0;                                              // inverses of the diagonal 16 x 16 blocks: [nb][4][16][16] per matrix (not cleared)
+    for (int b = 0; b < B; ++b) linv_doubles += (size_t)nbs[b] * 1024;
+    if (linv_doubles > q.linv_cap) {
+        if (q.linv) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(q.linv); q.linv = nullptr; }
+        ALABI_HIP_CHECK(hipMalloc(&q.linv, linv_doubles * sizeof(double)));
+        q.linv_cap = linv_doubles;
+    }
     std::vector<CholMat> hm(B);
-    size_t off = 256;
+    size_t off = 256, loff = 0;
     for (int b = 0; b < B; ++b) {
         hm[b].A = A[b]; hm[b].dinv = dinv[b]; hm[b].info = info[b]; hm[b].ld = ld[b]; hm[b].nb = nbs[b];
         hm[b].ver = q.ctl + off; hm[b].sver = q.ctl + off + (size_t)nbs[b] * nbs[b];
+        hm[b].linv = q.linv + loff;
         off += (size_t)nbs[b] * nbs[b] + nbs[b];
+        loff += (size_t)nbs[b] * 1024;
     }
     ALABI_HIP_CHECK(hipMemcpyAsync(q.mats, hm.data(), (size_t)B * sizeof(CholMat), hipMemcpyHostToDevice, s));
     ALABI_HIP_CHECK(hipStreamSynchronize(s));                             // `hm` is a local

@@ -89,6 +89,14 @@ class _SolverView:
     def log_determinant(self):
         return self._gp._logdet()
 
+    @property
+    def factor_path(self):
+        """How the last compute factorised: "steps" (launch per step), "queue" (one-launch task queue) or "queue-timeout"
+        (the queue's wait ran out; factorised again step by step)."""
+        out = C.c_int(0)
+        _lib.check(_lib.lib().alabi_gp_last_factor_path(self._gp._handle, C.byref(out)), "alabi_gp_last_factor_path")
+        return {0: None, 1: "steps", 2: "queue", 3: "queue-timeout"}[out.value]
+
     def get_factor(self):
         gp = self._gp
         gp._require_computed()

@@ -157,6 +157,9 @@ int alabi_gp_get_factor(alabi_gp* gp, double* L_out /* [N,N] row-major, upper pa
  * triangles, = W^T W on the matrix cores from the cached W = L^-1 of the current factor (built on demand). */
 int alabi_gp_get_inverse(alabi_gp* gp, double* Kinv_out, void* stream);
 int alabi_gp_n(alabi_gp* gp, int* n /* host */);
+/* How the last alabi_gp_compute factorised (tests, soak runs): 0 = not computed, 1 = launch per step, 2 = the one-launch task queue,
+ * 3 = the queue's wait ran out and the matrix was assembled and factorised again step by step. */
+int alabi_gp_last_factor_path(alabi_gp* gp, int* path /* host */);
 
 /* kernel.get_value(x1, x2) -- alabi/utility.py:549, :607.  K_out is [n1,n2] row-major,
  * no white noise. */

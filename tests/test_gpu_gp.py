@@ -643,6 +643,7 @@ def test_cholesky_panel_path(torch_gpu, monkeypatch, N, panel):
             monkeypatch.setenv("ALABI_CHOL_PANEL", env)
         monkeypatch.setenv("ALABI_CHOL_LOOKAHEAD", la)
         g = HipGP(6, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+        assert g.solver.factor_path == "steps"
         L = g.solver.get_factor().cpu().numpy()
         assert np.allclose(np.triu(L, 1), 0.0)
         assert np.max(np.abs(L @ L.T - K)) <= 1e-12 * np.max(np.abs(K)), tag
@@ -671,6 +672,7 @@ def test_cholesky_task_queue(torch_gpu, monkeypatch, N, waves):
     for tag, env in (("queue", "1"), ("steps", "0")):
         monkeypatch.setenv("ALABI_CHOL_TASKS", env)
         g = HipGP(6, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+        assert g.solver.factor_path == tag                    # (an earlier time-out's penalty does not apply when the queue is forced)
         L = g.solver.get_factor().cpu().numpy()
         assert np.allclose(np.triu(L, 1), 0.0)
         assert np.max(np.abs(L @ L.T - K)) <= 1e-12 * np.max(np.abs(K)), tag
@@ -692,6 +694,7 @@ def test_cholesky_task_queue(torch_gpu, monkeypatch, N, waves):
         monkeypatch.setenv("ALABI_CHOL_TASKS", "1")
         monkeypatch.setenv("ALABI_CHOL_SPIN_LIMIT", "1")
         g2 = HipGP(6, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g2.compute(X)
+        assert g2.solver.factor_path == "queue-timeout"
         assert np.array_equal(g2.solver.get_factor().cpu().numpy(), facs["steps"][0])
         monkeypatch.delenv("ALABI_CHOL_SPIN_LIMIT")
 

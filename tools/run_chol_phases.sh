@@ -1,0 +1,7 @@
+# Phase stamps of the task-queue Cholesky (ALABI_CHOL_PROF build: s_memrealtime inside the kernel; slower than the product build).
+# Run on the GPU box through gpurun; the product build is restored on exit.   usage: bash tools/run_chol_phases.sh [N ...]
+cd $GRAFT_REPO_ROOT
+restore() { (cd alabi_amd/csrc && rm -f gp_cholesky.o && make -j16 > /dev/null 2>&1); }
+trap restore EXIT
+(cd alabi_amd/csrc && rm -f gp_cholesky.o && make EXTRA=-DALABI_CHOL_PROF -j16 > /dev/null 2>&1) || exit 1
+ALABI_CHOL_TASKS=1 timeout -k 10 300 python tools/prof_chol_sizes.py ${@:-2000 10000} 2>&1 | grep -v amdgpu.ids
