@@ -670,6 +670,11 @@ __device__ inline void ct_fetch_slabs(const double* __restrict__ Lp, int ld, con
 // and wave, 40 per tile = 1.1 us, no cross-lane traffic and no barrier between the slabs.  The slabs of L[kk,kk] are taken as they are
 // published (sver[kk] = slabs available; all that are there in ONE fetch when the tile is final).  Error of a slab: that of a product
 // with the explicit inverse of a 16 x 16 block, eps cond(L_ss) -- the blocks are small, tests hold ||L L^T - K|| <= 1e-12 ||K||.
+// (Measured and not kept: the LAST inverse block polled itself -- pre-filled with a tag by the assembly kernel, valid once it differs -- instead
+// of through the slab counter, one memory round trip instead of three behind the producer's last store: N = 2000 0.492 vs 0.495 ms.  The event
+// log (ALABI_CHOL_LOG) shows why: the next CHAIN task gets its own tiles only 3 us before the previous factorisation ends -- they come from
+// the single-column updates behind the previous panel solve -- and then works through the slabs at two round trips each, poll and fetch:
+// slab 2 is in LDS 2 us AFTER that end, whatever the last block does.)
 // DIAG (CHAIN): tile (k,k), parked in ct_T2, takes - X X^T slab by slab behind the solve (its ten lower 16 x 16 tiles dealt to all
 // waves, accumulators in registers) and ends up in ct_T0 for the factorisation; the solved tile is written to Xdst while the last
 // of that runs.  Returns false when a wait ran out (err set, every thread leaves).
@@ -699,10 +704,10 @@ __device__ __attribute__((noinline)) bool ct_solve(const double* __restrict__ Lp
             __syncthreads();
             const int got = ct_task_s[9];
             if (got < 0) return false;
-            if constexpr (DIAG) { for (int q_ = S; q_ < got && q_ < 4; ++q_) CT_LOG(3 + q_); }
             have = got < 4 ? got : 4;                          // everything that is there, in one round trip
             ct_fetch_slabs<NT>(Lp, ld, linv, tid, S, have);
             __syncthreads();                                   // the slab(s) -- and at S = 0 the caller's tiles -- are in LDS
+            if constexpr (DIAG) { for (int q_ = S; q_ < have; ++q_) CT_LOG(3 + q_); }
         }
         if (w < 4) {
             if (S == 0) {
@@ -777,23 +782,113 @@ __device__ long long g_potrf_prof[8];                          // 10-ns ticks in
 // call to one) every CHAIN task saved and restored up to 79 registers through scratch memory -- the factorisation took 12-13 us instead of 9.
 // (Also measured and not kept: ONE non-inlined copy of the recurrence for every slab, with the slab offset at run time: 1.52 instead of
 // 1.26 us per slab.)
+// Inside the function the waves do not meet at barriers but follow each other through LDS words (ct_task_s[10..14]; every wait bounded):
+//   wave 0          the four slab recurrences; before recurrence s it waits until tile column s carries slab s - 1 ([12])
+//   wave 1          slab 0: rows 48..63 behind a copy of rows 0..15 ([13]: 1 = rows read, 2 = rows written back); then owner A
+//   owners A, B, C  (waves 1, 2 and 6 -- with four waves 3) the rank-16 updates of the trailing 16 x 16 tiles, every slab of a tile by ONE
+//                   wave in order: A (1,1) (2,2), B (2,1) (3,2), C (3,1) (3,3).  When slab s is in LDS ([11] = s + 1) an owner first updates its
+//                   tile of column s + 1 -- all the next recurrence needs; counted in [12] -- then its tiles further right, under that recurrence
+//   waves 3 (and 7) write slab s -- rows 16 s.., its columns (lower part), the inverse of its diagonal block, its reciprocals -- through to
+//                   memory in 16-byte pieces, wait for the stores to drain ([10]: wave 7's half) and publish sver = s + 1 ([14]: inverse
+//                   blocks read, before wave 0 reuses the buffer)
+// With two barriers per slab instead -- recurrence | stores + every trailing tile | next recurrence -- all eight waves waited 0.6-1.0 us
+// per slab for the two storing waves (write-through stores hold the issuing wave), the factorisation took 9.9 us for 4.8 us of recurrences.
+// Spinning waves share no SIMD with the recurrences of waves 0 and 1 (waves 4 and 5 sleep at the final barrier).
+#define CT_FLAG(i) (*(volatile __attribute__((address_space(3))) int*)&ct_task_s[i])
+__device__ inline bool ct_flag_wait(int i, int want, bool sleep) {
+    int spins = 0;
+    while (CT_FLAG(i) < want) {
+        if (++spins > (1 << 22)) return false;                 // (a protocol error, not a slow neighbour: every wave here makes progress on its own)
+        if (sleep) __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+__device__ inline void ct_flag_set(int i, int v, int lane) {      // (LDS operations of one wave are executed in order: the data first)
+    asm volatile("" ::: "memory");
+    if (lane == 0) CT_FLAG(i) = v;
+}
+__device__ inline void ct_flag_add(int i, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&ct_task_s[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, double* __restrict__ D, int ld, double* __restrict__ dinv,
-                                                            int* sver, double* __restrict__ linv) {
+                                                            int* sver, double* __restrict__ linv, int* err) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int nwm = (int)(blockDim.x >> 6) - 1;               // 3 or 7: the rank-16 tile updates between slabs are dealt to ALL waves of the workgroup
+    const bool eight = blockDim.x == 512;
     double* const inv_s = ct_pool + 3 * 64 * 66;              // T3: inverses of the slabs' diagonal blocks, [slab & 1][n][k]
     kb = __builtin_amdgcn_readfirstlane(kb);
-    if (tid == 0) ct_task_s[10] = 0;                          // (read two barriers from here at the earliest)
-    // owner of the 16 x 16 tile (ti, tk) of the trailing part, tk >= 1: one wave applies every slab to it, in order.  Column 1: waves 0, 1, 2;
-    // columns 2 and 3 (which receive slabs UNDER a recurrence of wave 0): waves 4, 5, 6 with eight waves, 1, 2, 1 with four
-    auto owner = [nwm](int ti, int tk) { return tk == 1 ? ti - 1 : nwm == 7 ? (tk == 2 ? ti + 2 : 6) : (tk == 2 ? ti - 1 : 1); };
+    if (tid < 5) ct_task_s[10 + tid] = 0;
+    __syncthreads();
+    bool ok = true;
+    // one owner's share of slab S: its tile of column S + 1 first (counted), then its tiles further right
+    auto owner_slab = [&](auto s_tag, int which) {
+        constexpr int S = decltype(s_tag)::value;
+        if (!ct_flag_wait(11, S + 1, true)) { ok = false; return; }
+        const int t1r = which + 1, t2r = which == 0 ? 2 : 3, t2c = which == 2 ? 3 : 2;    // (t1r, 1) and (t2r, t2c)
+        if (S == 0) {
+            tile_update_16<66>(ct_T0, 16 * t1r, 16, ct_T0, 16 * t1r, ct_T0, 16, 0, lane);
+            ct_flag_add(12, lane);
+            tile_update_16<66>(ct_T0, 16 * t2r, 16 * t2c, ct_T0, 16 * t2r, ct_T0, 16 * t2c, 0, lane);
+        } else if (t2c == S + 1) {
+            tile_update_16<66>(ct_T0, 16 * t2r, 16 * t2c, ct_T0, 16 * t2r, ct_T0, 16 * t2c, 16 * S, lane);
+            ct_flag_add(12, lane);
+        } else if (t2c > S + 1) {
+            tile_update_16<66>(ct_T0, 16 * t2r, 16 * t2c, ct_T0, 16 * t2r, ct_T0, 16 * t2c, 16 * S, lane);
+        }
+    };
+    // the storing waves' share of slab S
+    auto store_slab = [&](auto s_tag) {
+        constexpr int S = decltype(s_tag)::value;
+        constexpr int c0 = 16 * S;
+        if (!ct_flag_wait(11, S + 1, true)) { ok = false; return; }
+        const __amdgpu_buffer_rsrc_t rs = ct_block_rsrc(D, ld);
+        ct_u32x4 v[8], iv[2];                                  // every LDS read first (see tile_store_sc1); rows >= c0: p_ >= 2 S
+        double dl = 1.0;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int c0 = 16 * s;
-#ifdef ALABI_CHOL_PROF
-        const long long pq_ = __builtin_amdgcn_s_memrealtime();
-#endif
-        if (w == 0) {
+        for (int p_ = 2 * S; p_ < 8; ++p_) {
+            const int e = lane + 64 * p_;
+            v[p_] = *reinterpret_cast<const ct_u32x4*>(&ct_T0[e >> 3][c0 + 2 * (e & 7)]);
+        }
+        if (w == 3) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) iv[q] = *reinterpret_cast<const ct_u32x4*>(&inv_s[256 * (S & 1) + 2 * (lane + 64 * q)]);
+            dl = ct_T0[c0 + (lane & 15)][c0 + (lane & 15)];
+        }
+#pragma unroll
+        for (int p_ = 2 * S; p_ < 8; ++p_) asm volatile("" : "+v"(v[p_]));
+        if (w == 3) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(iv[q]));
+            ct_flag_set(14, S + 1, lane);
+        }
+#pragma unroll
+        for (int p_ = 2 * S; p_ < 8; ++p_) {
+            const int e = lane + 64 * p_;
+            if (!eight || (p_ & 1) == (w >> 2)) ct_store_pair(rs, ld, e >> 3, c0 + 2 * (e & 7), v[p_], true);
+        }
+        if (w == 3) {
+            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(linv, 0, 8192u, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) __builtin_amdgcn_raw_buffer_store_b128(iv[q], rl, (unsigned)(S * 256 + 2 * (lane + 64 * q)) * 8u, 0, 16);
+            if (lane < 16)
+                __hip_atomic_store(ct_g64(dinv + kb * 64 + c0 + lane), (unsigned long long)__double_as_longlong(potrf_dinv(dl)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (w == 7) ct_flag_set(10, S + 1, lane);
+        else {
+            if (eight && !ct_flag_wait(10, S + 1, true)) { ok = false; return; }
+            if (lane == 0) __hip_atomic_store(ct_g32(sver), S + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (S == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // in front of the "4" below
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    if (w == 0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int c0 = 16 * s;
+            if (s > 0 && ok) ok = ct_flag_wait(12, s == 1 ? 3 : s == 2 ? 5 : 6, false);   // tile column s carries slab s - 1
             double a[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) a[j] = ct_T0[lane][c0 + j];
@@ -802,24 +897,10 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
 #pragma unroll
                 for (int j = 0; j < 16; ++j) a[j] = (il >= 0 && il < 16) ? (j == il ? 1.0 : 0.0) : a[j];
             }
-            if (s == 0) __syncthreads();                       // wave 1 has read rows 0..15 before this wave writes them back
-#ifdef ALABI_CHOL_PROF
-            long long q0_, q1_;
-            {   // stamps that depend on the data: after the slab is in registers / after its last entry is final
-                const int dep_ = __builtin_amdgcn_readfirstlane(__double2hiint(a[0]) ^ __double2hiint(a[15]));
-                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q0_) : "s"(dep_) : "memory");
-                asm volatile("" : "+v"(a[0]), "+v"(a[15]) : "s"(q0_));
-            }
-#endif
             potrf_slab(a, c0);
-#ifdef ALABI_CHOL_PROF
-            {
-                const int dep_ = __builtin_amdgcn_readfirstlane(__double2hiint(a[15]));
-                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q1_) : "s"(dep_) : "memory");
-            }
-            if (lane == 0) { g_potrf_prof[0] += q1_ - q0_; g_potrf_prof[1] += 1; }
-#endif
             CT_LOG(10 + s);
+            if (s == 0 && ok) ok = ct_flag_wait(13, 1, false);        // wave 1 has read rows 0..15 before they are written back
+            if (s >= 2 && ok) ok = ct_flag_wait(14, s - 1, false);    // wave 3 has read block s - 2 out of this half of the buffer
             if (s > 0 ? lane < 16 : lane >= 48) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) inv_s[256 * (s & 1) + j * 16 + (lane & 15)] = a[j];   // identity lane i holds row i of inv(L_ss)^T
@@ -827,7 +908,9 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
 #pragma unroll
                 for (int j = 0; j < 16; ++j) ct_T0[lane][c0 + j] = a[j];
             }
-            if (s == 3) {                                      // (LDS operations of one wave are executed in order)
+            if (s == 0 && ok) ok = ct_flag_wait(13, 2, false);        // rows 48..63 of slab 0 are in LDS too
+            if (s < 3) ct_flag_set(11, s + 1, lane);
+            else {                                             // the last inverse block is all the next panel solve waits for: out at once
                 const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(linv, 0, 8192u, 0x00020000);
                 ct_u32x4 iv[2];
 #pragma unroll
@@ -839,97 +922,34 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 CT_LOG(14);
             }
-        } else if (w == 1 && s == 0) {                         // rows 48..63 of slab 0 (lanes 16..31) behind a copy of rows 0..15 (lanes 0..15)
+        }
+    } else if (w == 1) {
+        {                                                      // rows 48..63 of slab 0 (lanes 16..31) behind a copy of rows 0..15 (lanes 0..15)
             double a[16];
             const int row = (lane & 16) ? 48 + (lane & 15) : (lane & 15);
 #pragma unroll
             for (int j = 0; j < 16; ++j) a[j] = ct_T0[row][j];
 #pragma unroll
             for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(a[j]));   // (the loads have landed)
-            __syncthreads();
+            ct_flag_set(13, 1, lane);
             potrf_slab(a, 0);
             if (lane >= 16 && lane < 32) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) ct_T0[row][j] = a[j];
             }
-        } else if (s == 0) {
-            __syncthreads();                                   // (the barrier between wave 1's reads and wave 0's writes, see above)
-        } else {
-            // the storing waves (below): their halves of slab s - 1 have drained -> wave 3 publishes the slab
-            if (w == 7) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) *(volatile __attribute__((address_space(3))) int*)&ct_task_s[10] = s;
-            } else if (w == 3) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (nwm == 7) while (*(volatile __attribute__((address_space(3))) int*)&ct_task_s[10] < s) __builtin_amdgcn_s_sleep(1);
-                if (lane == 0) __hip_atomic_store(ct_g32(sver), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (s == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // in front of the "4" below
-            }
-            // the rest of slab s - 1's rank-16 update -- the tiles right of tile column s, which the coming recurrence neither reads nor
-            // writes -- under that recurrence, each tile by its owner (who applied the earlier slabs to it and will apply the next)
-#pragma unroll
-            for (int tk = s + 1; tk < 4; ++tk)
-#pragma unroll
-                for (int ti = tk; ti < 4; ++ti)
-                    if (owner(ti, tk) == w) tile_update_16<66>(ct_T0, 16 * ti, 16 * tk, ct_T0, 16 * ti, ct_T0, 16 * tk, c0 - 16, lane);
+            ct_flag_set(13, 2, lane);
         }
-#ifdef ALABI_CHOL_PROF
-        if (s == 3 && tid == 0) { g_potrf_prof[4] += __builtin_amdgcn_s_memrealtime() - pq_; g_potrf_prof[5] += 1; }
-#endif
-        if (s == 3) break;
-        __syncthreads();
-        CT_LOG(16 + 2 * s);
-#ifdef ALABI_CHOL_PROF
-        const long long pa_ = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) g_potrf_prof[2] += pa_ - pq_;
-#endif
-        // The slab goes out: rows c0.., its columns (lower part), the inverse of its diagonal block and its reciprocals -- by wave 3, with eight
-        // waves by waves 3 and 7 in halves, in 16-byte pieces.  Write-through stores leave a CU at ~9 GB/s however many waves issue them and
-        // the issuing wave stalls meanwhile, so the 7 KB of slab 0 hold these two waves -- and, at the barrier below, everyone -- for 0.8 us
-        // (measured and not kept: four storing waves on four SIMDs, no faster; the stores UNDER the next recurrence instead, published
-        // when drained: the factorisation 9.9 -> 9.4 us, but every panel solve that waits for the slab waits 1.3 us longer -- a single
-        // matrix of N = 2000 the same 0.50 ms, 500 matrices of N = 1600 26.6 instead of 23.4 ms).
-        if (w == 3 || w == 7) {
-            const __amdgpu_buffer_rsrc_t rs = ct_block_rsrc(D, ld);
-            ct_u32x4 v[8], iv[2];                              // every LDS read first (see tile_store_sc1); rows >= c0: p_ >= 2 s
-            double dl = 1.0;
-#pragma unroll
-            for (int p_ = 2 * s; p_ < 8; ++p_) {
-                const int e = lane + 64 * p_;
-                v[p_] = *reinterpret_cast<const ct_u32x4*>(&ct_T0[e >> 3][c0 + 2 * (e & 7)]);
-            }
-            if (w == 3) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) iv[q] = *reinterpret_cast<const ct_u32x4*>(&inv_s[256 * (s & 1) + 2 * (lane + 64 * q)]);
-                dl = ct_T0[c0 + (lane & 15)][c0 + (lane & 15)];
-            }
-#pragma unroll
-            for (int p_ = 2 * s; p_ < 8; ++p_) asm volatile("" : "+v"(v[p_]));
-#pragma unroll
-            for (int p_ = 2 * s; p_ < 8; ++p_) {
-                const int e = lane + 64 * p_;
-                if (nwm != 7 || (p_ & 1) == (w >> 2)) ct_store_pair(rs, ld, e >> 3, c0 + 2 * (e & 7), v[p_], true);
-            }
-            if (w == 3) {
-                const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(linv, 0, 8192u, 0x00020000);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) __builtin_amdgcn_raw_buffer_store_b128(iv[q], rl, (unsigned)(s * 256 + 2 * (lane + 64 * q)) * 8u, 0, 16);
-                if (lane < 16)
-                    __hip_atomic_store(ct_g64(dinv + kb * 64 + c0 + lane), (unsigned long long)__double_as_longlong(potrf_dinv(dl)),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        // the slab's rank-16 update of tile column s + 1 -- all the next recurrence needs (one tile per wave: 0.5 us; the whole trailing
-        // part, six tiles at s = 0, took 1.1 us between these barriers); the other tiles follow under that recurrence, above
-#pragma unroll
-        for (int ti = s + 1; ti < 4; ++ti)
-            if (owner(ti, s + 1) == w) { tile_update_16<66>(ct_T0, 16 * ti, 16 * (s + 1), ct_T0, 16 * ti, ct_T0, 16 * (s + 1), c0, lane); if (ti == s + 1) CT_LOGW(28 + s); }
-        __syncthreads();
-        CT_LOG(17 + 2 * s);
-#ifdef ALABI_CHOL_PROF
-        if (tid == 0) g_potrf_prof[3] += __builtin_amdgcn_s_memrealtime() - pa_;
-#endif
+        owner_slab(I0{}, 0); owner_slab(I1{}, 0);
+    } else if (w == 2) {
+        owner_slab(I0{}, 1); owner_slab(I1{}, 1);
+    } else if (eight ? w == 6 : w == 3) {
+        owner_slab(I0{}, 2); if (!eight) store_slab(I0{});
+        owner_slab(I1{}, 2); if (!eight) store_slab(I1{});
+        owner_slab(I2{}, 2); if (!eight) store_slab(I2{});
+    } else if (w == 3 || w == 7) {
+        store_slab(I0{}); store_slab(I1{}); store_slab(I2{});
     }
+    if (!ok && lane == 0) __hip_atomic_store(ct_g32(err), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     // every slab and every inverse block is out (wave 3 drained slab 2 before it published it, wave 0 block 3 above): the panel solves
     // need nothing else of this tile -- not the last diagonal block, which goes out with the whole tile behind this
@@ -1510,7 +1530,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
             p4 = __builtin_amdgcn_s_memrealtime();
 #endif
             CT_LOG(9);
-            const double rinv = ct_potrf_publish(tk, info, D, ld, dinv, sver + tk, linv + (size_t)tk * 1024);
+            const double rinv = ct_potrf_publish(tk, info, D, ld, dinv, sver + tk, linv + (size_t)tk * 1024, err);
 #ifdef ALABI_CHOL_PROF
             const long long p5 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1799,12 +1819,16 @@ int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
             for (int k = k0; k <= k1; ++k) sum += 0.01 * (double)(h[k][i + 1] - h[k][i]);
             fprintf(stderr, "  %-44s %7.2f\n", name[i], sum / (k1 - k0 + 1));
         }
-        for (int sl = 0; sl < 3; ++sl) {
-            double r2a = 0, a2b = 0, b2r = 0;
-            for (int k = k0; k <= k1; ++k) { r2a += 0.01 * (double)(h[k][16 + 2 * sl] - h[k][10 + sl]); a2b += 0.01 * (double)(h[k][17 + 2 * sl] - h[k][16 + 2 * sl]); b2r += 0.01 * (double)(h[k][11 + sl] - h[k][17 + 2 * sl]); }
-            double wt = 0;
-            for (int k = k0; k <= k1; ++k) wt += 0.01 * (double)(h[k][28 + sl] - h[k][16 + 2 * sl]);
-            fprintf(stderr, "  slab %d: recurrence done -> past barrier A %.2f, A -> B (stores, tile updates) %.2f (diagonal tile updated after %.2f), B -> next recurrence done %.2f\n", sl, r2a / (k1 - k0 + 1), a2b / (k1 - k0 + 1), wt / (k1 - k0 + 1), b2r / (k1 - k0 + 1));
+        {
+            double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int k = k0; k <= k1; ++k) {
+                const long long r3 = h[k - 1][13];              // the producer's last recurrence done
+                t[0] += 0.01 * (double)(h[k][3] - r3); t[1] += 0.01 * (double)(h[k][4] - r3); t[2] += 0.01 * (double)(h[k][5] - r3); t[3] += 0.01 * (double)(h[k][6] - r3);
+                t[4] += 0.01 * (double)(h[k][7] - r3); t[5] += 0.01 * (double)(h[k][9] - r3); t[6] += 0.01 * (double)(h[k - 1][14] - r3); t[7] += 0.01 * (double)(h[k][2] - r3);
+            }
+            const double n_ = k1 - k0 + 1;
+            fprintf(stderr, "  relative to the END of the previous CHAIN's last recurrence: tiles in LDS %+.2f; slab 0 / 1 / 2 / 3 in LDS %+.2f %+.2f %+.2f %+.2f; solve + diag update done %+.2f; "
+                            "factorisation starts %+.2f (the previous CHAIN's last inverse block drained at %+.2f)\n", t[7] / n_, t[0] / n_, t[1] / n_, t[2] / n_, t[3] / n_, t[4] / n_, t[5] / n_, t[6] / n_);
         }
         double per = 0, hop = 0;
         for (int k = k0; k <= k1; ++k) { per += 0.01 * (double)(h[k + 1][9] - h[k][9]); hop += 0.01 * (double)(h[k + 1][6] - h[k][14]); }
