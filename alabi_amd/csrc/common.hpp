@@ -186,7 +186,7 @@ struct CholBatchQueue {
     int* list_off = nullptr;                    // device [nlists + 1]
     CholMat* mats = nullptr; size_t mats_cap = 0;
     int* ctl = nullptr; size_t ctl_ints = 0, ctl_cap = 0;   // [32 q] list heads, [1] time-out flag, from [256] on: per matrix tile versions + slab counters
-    double* linv = nullptr; size_t linv_cap = 0;            // per matrix [nb][4][16][16]: inverses of the diagonal 16 x 16 blocks (matrix-core panel solves)
+    double* linv = nullptr; size_t linv_cap = 0;            // per matrix the slab buffers [nb][4][64][16] (gp_cholesky.hip: what the panel solves read of a diagonal tile)
 };
 int chol_batch_prepare(CholBatchQueue& q, int B, const int* ld, double* const* A, double* const* dinv, int* const* info, hipStream_t s);
 int chol_batch_launch(CholBatchQueue& q, hipStream_t s);

@@ -39,6 +39,11 @@ assemble_lower_kernel(const double* __restrict__ Xt, int N, int Npad, int d, dou
     // the factorisation's control words (task-queue head, time-out flag, tile versions) and its status word start at zero:
     // cleared here instead of by two memset nodes in front of the factorisation kernel
     for (int i = blockIdx.x * 256 + threadIdx.x; i < zero_ints; i += gridDim.x * 256) zero[i] = 0;
+    // ... and the slab buffers behind them (gp_cholesky.hip: [nb][4][64][16] doubles) start as the tag the panel solves poll them for
+    if (zero_ints > 0) {
+        const int nbt = Npad / 64, base = (zero_ints + 1) & ~1;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nbt * 8192; i += gridDim.x * 256) zero[base + i] = (int)0x7FF8DEADu;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) *info = 0;
     // linear tile id -> (bi >= bj)
     int t = blockIdx.x;

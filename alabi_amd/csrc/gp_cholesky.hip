@@ -623,40 +623,40 @@ __shared__ int ct_log_kb;
 #endif
 // Lower-triangle tile j of the 4 x 4 grid of 16 x 16 tiles of a diagonal tile: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) (3,0) .. (3,3)
 __device__ inline void ct_diag_tile(int j, int& rt, int& ct) { rt = j >= 6 ? 3 : j >= 3 ? 2 : j >= 1 ? 1 : 0; ct = j - rt * (rt + 1) / 2; }
-// The slabs [s0, s1) of L[kk,kk] into ct_T0 in ONE memory round trip (a coherent load takes 0.7-1 us, whatever it fetches): of slab q
-// the rows below its diagonal block (L[t,q], t > q: what the solve applies to the later slabs) and, IN PLACE of the diagonal block, its
-// inverse from `linv` ([4][16][16], row-major) -- the solve never reads L[q,q].  One copy of the code: the bounds are run-time values.
+// What a panel solve needs of L[kk,kk] travels through the column's SLAB BUFFER, sbuf[4][64][16] doubles (32 KB per block column, beside the
+// matrix): slab s holds, in rows 16 s .. 16 s + 15, the INVERSE of the slab's diagonal block and below them the slab's columns of L (rows above
+// are unused) -- contiguous, in 16-byte pieces, piece e of a slab = row e >> 3, columns 2 (e & 7) ..  The solve never reads L[s,s] itself; in
+// ct_T0 the inverse stands in its place.
+#define ALABI_CHOL_TAG 0x7FF8DEADu   // both 32-bit halves of a "not written yet" double of the slab buffer: a NaN no arithmetic produces
 template <int NT>
-__device__ inline void ct_fetch_slabs(const double* __restrict__ Lp, int ld, const double* __restrict__ linv, int tid, int s0, int s1) {
-    constexpr int NE = 1024 / NT;
-    unsigned long long v[3][NE], iv[4];
+__device__ inline ct_u32x4 ct_slab_piece(__amdgpu_buffer_rsrc_t rs, int q, int e) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(q * 1024 + 2 * e) * 8u, 0, 16);
+}
+__device__ inline void ct_slab_piece_put(int q, int e, ct_u32x4 v) { *reinterpret_cast<ct_u32x4*>(&ct_T0[e >> 3][16 * q + 2 * (e & 7)]) = v; }
+// the slabs [s0, s1) into ct_T0 in ONE memory round trip (a coherent load takes 0.7-1 us, whatever it fetches); run-time bounds: one copy of the code
+template <int NT>
+__device__ inline void ct_fetch_slabs(const double* __restrict__ sbuf, int tid, int s0, int s1) {
+    constexpr int NE = 512 / NT;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(sbuf), 0, 32768u, 0x00020000);
+    ct_u32x4 v[4][NE];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 4; ++q)
         if (q >= s0 && q < s1) {
-            if (q < 3) {
 #pragma unroll
-                for (int e_ = 0; e_ < NE; ++e_) {
-                    const int e = tid + NT * e_, r = e >> 4, c = 16 * q + (e & 15);
-                    if (r >= 16 * (q + 1))
-                        v[q < 3 ? q : 0][e_] = __hip_atomic_load(ct_g64(Lp + (size_t)r * ld + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            for (int e_ = 0; e_ < NE; ++e_) {
+                const int e = tid + NT * e_;
+                if ((e >> 3) >= 16 * q) v[q][e_] = ct_slab_piece<NT>(rs, q, e);
             }
-            if (tid < 256) iv[q] = __hip_atomic_load(ct_g64(linv + q * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 4; ++q)
         if (q >= s0 && q < s1) {
-            if (q < 3) {
 #pragma unroll
-                for (int e_ = 0; e_ < NE; ++e_) {
-                    const int e = tid + NT * e_, r = e >> 4, c = 16 * q + (e & 15);
-                    if (r >= 16 * (q + 1)) ct_T0[r][c] = __longlong_as_double((long long)v[q < 3 ? q : 0][e_]);
-                }
+            for (int e_ = 0; e_ < NE; ++e_) {
+                const int e = tid + NT * e_;
+                if ((e >> 3) >= 16 * q) ct_slab_piece_put(q, e, v[q][e_]);
             }
-            if (tid < 256) ct_T0[16 * q + (tid >> 4)][16 * q + (tid & 15)] = __longlong_as_double((long long)iv[q]);
         }
-    }
 }
 // Panel solve X L_kk^T = B of the tile in ct_T1 ENTIRELY ON THE MATRIX CORES (round 4; before: a 16-step recurrence per slab in one
 // wave, 1.8 us per slab, 7.2 us per tile -- 30 % of the workgroup time of a batch of N = 1600 matrices and the tail of every CHAIN).
@@ -678,15 +678,66 @@ __device__ inline void ct_fetch_slabs(const double* __restrict__ Lp, int ld, con
 // DIAG (CHAIN): tile (k,k), parked in ct_T2, takes - X X^T slab by slab behind the solve (its ten lower 16 x 16 tiles dealt to all
 // waves, accumulators in registers) and ends up in ct_T0 for the factorisation; the solved tile is written to Xdst while the last
 // of that runs.  Returns false when a wait ran out (err set, every thread leaves).
-template <int NT, bool DIAG>
-__device__ __attribute__((noinline)) bool ct_solve(const double* __restrict__ Lp, int ld, const double* __restrict__ linv, int* sver, int* err,
+// TAG (single matrix): no counter is polled at all.  The assembly kernel fills the slab buffers with a tag; the solve requests ALL FOUR slabs
+// at once when it starts, and a slab counts as there when none of its pieces carries the tag any more (8 bytes at a time; a piece that
+// does is requested again) -- one memory round trip behind the producer's stores instead of three (drain + counter, poll, fetch), and the
+// slabs that were there already cost no round trip of their own.  (The event log, ALABI_CHOL_LOG, had shown the chain's next step getting its
+// own tiles only 3 us before the previous factorisation ended, and then working through the slabs at two round trips each: the last slab was in
+// LDS 4 us after that end.)  !TAG (batch): sver[kk] = slabs published so far, polled; everything that is there fetched in one round trip.
+template <int NT, bool DIAG, bool TAG>
+__device__ __attribute__((noinline)) bool ct_solve(int ld, const double* __restrict__ sbuf, int* sver, int* err,
                                                    int spin_limit, int ntasks, double* __restrict__ Xdst) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
     constexpr int NW = NT / 64, NQ = (10 + NW - 1) / NW;       // lower 16 x 16 tiles of the diagonal tile per wave: 3 (four waves) / 2 (eight)
+    constexpr int NE = 512 / NT;                               // 16-byte pieces of a slab per thread
     v4f64 Y[4], dacc[NQ];
     int have = 0;                                              // slabs of L[kk,kk] in ct_T0
+    ct_u32x4 pv[4][NE];
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(sbuf), 0, 32768u, 0x00020000);
+    if constexpr (TAG) {
+        if (tid == 0) ct_task_s[15] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e_ = 0; e_ < NE; ++e_) {
+                const int e = tid + NT * e_;
+                if ((e >> 3) >= 16 * q) pv[q][e_] = ct_slab_piece<NT>(prs, q, e);
+            }
+    }
     auto slab = [&](auto s_tag) -> bool {
         constexpr int S = decltype(s_tag)::value;
+        if constexpr (TAG) {
+            int spins = 0;
+            for (;;) {
+                bool good = true;
+#pragma unroll
+                for (int e_ = 0; e_ < NE; ++e_) {
+                    const int e = tid + NT * e_;
+                    const ct_u32x4 v = pv[S][e_];
+                    if ((e >> 3) >= 16 * S && ((v.x == ALABI_CHOL_TAG && v.y == ALABI_CHOL_TAG) || (v.z == ALABI_CHOL_TAG && v.w == ALABI_CHOL_TAG))) good = false;
+                }
+                if (__all(good)) break;
+                if (++spins > spin_limit || ((spins & 63) == 0 && __hip_atomic_load(ct_g32(err), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    if (l == 0) { __hip_atomic_store(ct_g32(err), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ct_task_s[4] = ntasks; ct_task_s[15] = 1; }
+                    break;
+                }
+                asm volatile("" ::: "memory");                   // (a fresh load every time round: the builtin is not volatile)
+#pragma unroll
+                for (int e_ = 0; e_ < NE; ++e_) {
+                    const int e = tid + NT * e_;
+                    if ((e >> 3) >= 16 * S) pv[S][e_] = ct_slab_piece<NT>(prs, S, e);
+                }
+            }
+#pragma unroll
+            for (int e_ = 0; e_ < NE; ++e_) {
+                const int e = tid + NT * e_;
+                if ((e >> 3) >= 16 * S) ct_slab_piece_put(S, e, pv[S][e_]);
+            }
+            __syncthreads();                                   // the slab -- and at S = 0 the caller's tiles -- are in LDS
+            if (ct_task_s[15] != 0) return false;
+            if constexpr (DIAG) CT_LOG(3 + S);
+            have = S + 1;
+        }
         if (have <= S) {
             if (tid == 0) {
                 int v, spins = 0;
@@ -705,7 +756,7 @@ __device__ __attribute__((noinline)) bool ct_solve(const double* __restrict__ Lp
             const int got = ct_task_s[9];
             if (got < 0) return false;
             have = got < 4 ? got : 4;                          // everything that is there, in one round trip
-            ct_fetch_slabs<NT>(Lp, ld, linv, tid, S, have);
+            ct_fetch_slabs<NT>(sbuf, tid, S, have);
             __syncthreads();                                   // the slab(s) -- and at S = 0 the caller's tiles -- are in LDS
             if constexpr (DIAG) { for (int q_ = S; q_ < have; ++q_) CT_LOG(3 + q_); }
         }
@@ -842,39 +893,27 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
         constexpr int S = decltype(s_tag)::value;
         constexpr int c0 = 16 * S;
         if (!ct_flag_wait(11, S + 1, true)) { ok = false; return; }
-        const __amdgpu_buffer_rsrc_t rs = ct_block_rsrc(D, ld);
-        ct_u32x4 v[8], iv[2];                                  // every LDS read first (see tile_store_sc1); rows >= c0: p_ >= 2 S
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(linv, 0, 32768u, 0x00020000);   // the column's slab buffer
+        ct_u32x4 v[8];                                         // every LDS read first (see tile_store_sc1); piece e = lane + 64 p_: row e >> 3 >= c0
         double dl = 1.0;
 #pragma unroll
         for (int p_ = 2 * S; p_ < 8; ++p_) {
-            const int e = lane + 64 * p_;
-            v[p_] = *reinterpret_cast<const ct_u32x4*>(&ct_T0[e >> 3][c0 + 2 * (e & 7)]);
+            const int e = lane + 64 * p_, r = e >> 3, c = 2 * (e & 7);
+            if (p_ < 2 * S + 2) { if (w == 3) v[p_] = *reinterpret_cast<const ct_u32x4*>(&inv_s[256 * (S & 1) + (r - c0) * 16 + c]); }   // rows c0 .. c0 + 15: the inverse block (wave 3 alone: [14])
+            else v[p_] = *reinterpret_cast<const ct_u32x4*>(&ct_T0[r][c0 + c]);
         }
-        if (w == 3) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) iv[q] = *reinterpret_cast<const ct_u32x4*>(&inv_s[256 * (S & 1) + 2 * (lane + 64 * q)]);
-            dl = ct_T0[c0 + (lane & 15)][c0 + (lane & 15)];
-        }
+        if (w == 3) dl = ct_T0[c0 + (lane & 15)][c0 + (lane & 15)];
 #pragma unroll
         for (int p_ = 2 * S; p_ < 8; ++p_) asm volatile("" : "+v"(v[p_]));
-        if (w == 3) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(iv[q]));
-            ct_flag_set(14, S + 1, lane);
-        }
+        if (w == 3) ct_flag_set(14, S + 1, lane);
 #pragma unroll
         for (int p_ = 2 * S; p_ < 8; ++p_) {
             const int e = lane + 64 * p_;
-            if (!eight || (p_ & 1) == (w >> 2)) ct_store_pair(rs, ld, e >> 3, c0 + 2 * (e & 7), v[p_], true);
+            if (p_ < 2 * S + 2 ? w == 3 : (!eight || (p_ & 1) == (w >> 2))) __builtin_amdgcn_raw_buffer_store_b128(v[p_], rs, (unsigned)(S * 1024 + 2 * e) * 8u, 0, 16);
         }
-        if (w == 3) {
-            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(linv, 0, 8192u, 0x00020000);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) __builtin_amdgcn_raw_buffer_store_b128(iv[q], rl, (unsigned)(S * 256 + 2 * (lane + 64 * q)) * 8u, 0, 16);
-            if (lane < 16)
-                __hip_atomic_store(ct_g64(dinv + kb * 64 + c0 + lane), (unsigned long long)__double_as_longlong(potrf_dinv(dl)),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (w == 3 && lane < 16)
+            __hip_atomic_store(ct_g64(dinv + kb * 64 + c0 + lane), (unsigned long long)__double_as_longlong(potrf_dinv(dl)),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (w == 7) ct_flag_set(10, S + 1, lane);
         else {
@@ -911,14 +950,15 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
             if (s == 0 && ok) ok = ct_flag_wait(13, 2, false);        // rows 48..63 of slab 0 are in LDS too
             if (s < 3) ct_flag_set(11, s + 1, lane);
             else {                                             // the last inverse block is all the next panel solve waits for: out at once
-                const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(linv, 0, 8192u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(linv, 0, 32768u, 0x00020000);
                 ct_u32x4 iv[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) iv[q] = *reinterpret_cast<const ct_u32x4*>(&inv_s[256 + 2 * (lane + 64 * q)]);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(iv[q]));
 #pragma unroll
-                for (int q = 0; q < 2; ++q) __builtin_amdgcn_raw_buffer_store_b128(iv[q], rl, (unsigned)(3 * 256 + 2 * (lane + 64 * q)) * 8u, 0, 16);
+                for (int q = 0; q < 2; ++q)                    // slab 3 of the slab buffer, rows 48..63
+                    __builtin_amdgcn_raw_buffer_store_b128(iv[q], rl, (unsigned)(3 * 1024 + 48 * 16 + 2 * (lane + 64 * q)) * 8u, 0, 16);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 CT_LOG(14);
             }
@@ -1038,7 +1078,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
     double* A = A_; int ld = ld_, nb = nb_; int* info = info_; double* dinv = dinv_;
     int* head = ctl; int* err = ctl + 1; int* ver = ctl + 2;          // ver[i * nb + j]
     int* sver = ctl + 2 + nb * nb;                                    // sver[k]: slabs of L[k,k] published so far (0..4)
-    double* linv = BATCH ? nullptr : reinterpret_cast<double*>(ctl + ((2 + nb * nb + nb + 130 + 1) & ~1));   // [nb][4][16][16]: inverses of the diagonal 16 x 16 blocks
+    double* linv = BATCH ? nullptr : reinterpret_cast<double*>(ctl + ((2 + nb * nb + nb + 130 + 1) & ~1));   // the slab buffers, [nb][4][64][16] (ct_fetch_slabs)
     int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
     __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(A, 0, (unsigned)ld * (unsigned)ld * 8u, 0x00020000);
     if constexpr (BATCH) {
@@ -1483,7 +1523,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
                 tile_fetch<NT>(rb, A + (size_t)(ti * 64) * ld + tk * 64, ld, tid);
                 tile_put<NT>(T1, rb, tid);
             }
-            if (!ct_solve<NT, false>(A + (size_t)(tk * 64) * ld + tk * 64, ld, linv + (size_t)tk * 1024, sver + tk, err, spin_limit, ntasks,
+            if (!ct_solve<NT, false, !BATCH>(ld, linv + (size_t)tk * 4096, sver + tk, err, spin_limit, ntasks,
                                      A + (size_t)(ti * 64) * ld + tk * 64)) return;
             publish_version(ver + ti * nb + tk, tk + 1, tid);
         } else {
@@ -1511,7 +1551,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
                 CT_LOG(2);
                 // the panel solve on the matrix cores, slab by slab as CHAIN(k-1) publishes the slabs of L[k-1,k-1] and the inverses of their
                 // diagonal blocks (bounded wait each); tile (k,k) -= X X^T follows it one slab behind and ends up in T0 (ct_solve)
-                if (!ct_solve<NT, true>(A + (size_t)((tk - 1) * 64) * ld + (tk - 1) * 64, ld, linv + (size_t)(tk - 1) * 1024, sver + tk - 1, err,
+                if (!ct_solve<NT, true, !BATCH>(ld, linv + (size_t)(tk - 1) * 4096, sver + tk - 1, err,
                                         spin_limit, ntasks, A + (size_t)(tk * 64) * ld + (tk - 1) * 64)) return;
 #ifdef ALABI_CHOL_PROF
                 p2 = __builtin_amdgcn_s_memrealtime();
@@ -1530,7 +1570,7 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
             p4 = __builtin_amdgcn_s_memrealtime();
 #endif
             CT_LOG(9);
-            const double rinv = ct_potrf_publish(tk, info, D, ld, dinv, sver + tk, linv + (size_t)tk * 1024, err);
+            const double rinv = ct_potrf_publish(tk, info, D, ld, dinv, sver + tk, linv + (size_t)tk * 4096, err);
 #ifdef ALABI_CHOL_PROF
             const long long p5 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1745,8 +1785,8 @@ int cholesky_tasks_prepare(alabi_gp* gp, hipStream_t s, int* ctl_ints_out) {
     const bool forced_on = env && env[0] == '1', forced_off = env && env[0] == '0';
     if (nb < 3 || nb > 256 || forced_off || (!forced_on && (nb < 16 || nb > ALABI_CHOL_TASKS_MAX_NB))) return ALABI_OK;
     const size_t ctl_ints = 2 + (size_t)nb * nb + nb + 130;            // + 130: alignment + phase timers of an ALABI_CHOL_PROF build
-    // behind the control words (8-byte aligned, never cleared): the inverses of the diagonal 16 x 16 blocks, [nb][4][16][16] doubles
-    auto total_ints = [](size_t b) { return ((2 + b * b + b + 130 + 1) & ~(size_t)1) + b * 2048; };
+    // behind the control words (8-byte aligned; filled with the tag by the assembly kernel): the slab buffers, [nb][4][64][16] doubles
+    auto total_ints = [](size_t b) { return ((2 + b * b + b + 130 + 1) & ~(size_t)1) + b * 8192; };
     if (gp->chol_ctl_ints < total_ints(nb)) {
         if (gp->chol_ctl) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); ALABI_HIP_CHECK(hipFree(gp->chol_ctl)); gp->chol_ctl = nullptr; }
         const size_t cap_nb = gp->n_cap / 64 < 256 ? gp->n_cap / 64 : 256;
@@ -2092,8 +2132,8 @@ int chol_batch_prepare(CholBatchQueue& q, int B, const int* ld, double* const* A
         q.ctl_cap = ctl_ints;
     }
     q.ctl_ints = ctl_ints;
-    size_t linv_doubles = 0;                                              // inverses of the diagonal 16 x 16 blocks: [nb][4][16][16] per matrix (not cleared)
-    for (int b = 0; b < B; ++b) linv_doubles += (size_t)nbs[b] * 1024;
+    size_t linv_doubles = 0;                                              // the slab buffers, [nb][4][64][16] per matrix (not cleared: the batch polls the slab counters)
+    for (int b = 0; b < B; ++b) linv_doubles += (size_t)nbs[b] * 4096;
     if (linv_doubles > q.linv_cap) {
         if (q.linv) { ALABI_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(q.linv); q.linv = nullptr; }
         ALABI_HIP_CHECK(hipMalloc(&q.linv, linv_doubles * sizeof(double)));
@@ -2106,7 +2146,7 @@ int chol_batch_prepare(CholBatchQueue& q, int B, const int* ld, double* const* A
         hm[b].ver = q.ctl + off; hm[b].sver = q.ctl + off + (size_t)nbs[b] * nbs[b];
         hm[b].linv = q.linv + loff;
         off += (size_t)nbs[b] * nbs[b] + nbs[b];
-        loff += (size_t)nbs[b] * 1024;
+        loff += (size_t)nbs[b] * 4096;
     }
     ALABI_HIP_CHECK(hipMemcpyAsync(q.mats, hm.data(), (size_t)B * sizeof(CholMat), hipMemcpyHostToDevice, s));
     ALABI_HIP_CHECK(hipStreamSynchronize(s));                             // `hm` is a local
