@@ -1092,6 +1092,10 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
     // (Measured and not kept, round 3: CHAIN(k) applying block column k-2 to its panel tile itself instead of waiting for the
     // one-column UPDATE(k,k-1,k-2) task -- N = 2000 0.55 -> 0.58 ms with four waves, 0.54 -> 0.55 with eight: the period of the
     // chain is set by the 64-pivot factorisation handing its slabs to the next panel solve, not by that task.)
+    // (Round 4, again with the matrix-core panel solves, tools/experiments/chol_chain_fused_lookahead.patch: the event log shows the next CHAIN task
+    // receiving its tiles only 2.6 us before the previous factorisation ends -- publish, poll, fetch, 64 k-steps, store, publish, poll, fetch
+    // behind the previous panel solve -- so the fused task reaches its dependencies 2.8 us earlier, but its own unpipelined update loop takes
+    // 4.7 us against the 1 us the tile fetch took: N = 2000 0.518 instead of 0.488 ms.  A pipelined loop would gain ~0.9 us of 13 per step.)
     // (Measured and not kept: a grouped UPDATE drawing the NEXT task under its last block column, to take the queue's atomic round
     // trip off the workgroup's path -- still deadlock-free, and the four-wave kernel gained 3 % at N >= 5000, but the eight-wave
     // kernel lost 1-9 % at every size: a CHAIN task drawn ahead waits for its holder.)
