@@ -687,9 +687,9 @@ def main():
                                                "flops_per_point": N * (2 * d + 3), "counters": pmc_summary("predict_mean_mfma_kernel<")}
             ch_tf = extras["cholesky_gflops"] / 1e3
             extras["roofline_cholesky"] = {"bound": "mfma", "achieved": ch_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": ch_tf / FP64_PEAK_TFLOPS, "kernel": "chol_tasks8_kernel (one launch, tile tasks with slab-wise hand-over, eight waves per workgroup; N^3/3 flops, assembly included in the time)",
+                                           "frac": ch_tf / FP64_PEAK_TFLOPS, "kernel": "chol_tasks8_kernel (one launch, tile tasks with slab-wise hand-over, panel solves on the matrix cores, eight waves per workgroup; N^3/3 flops, assembly included in the time)",
                                            "counters": pmc_summary("chol_tasks8_kernel", "min"),
-                                           "note": "N=2000 is latency-bound on the chain of 31 diagonal factorisations; the larger sizes are timed in extras.configs (C4: N=5000, C5: N=10000, chol_tasks8_kernel: 39 TFLOP/s; N=16000: 46 TFLOP/s; DESIGN.md par. 7, profiles/r03_cholesky_w8_vs_w4.txt)"}
+                                           "note": "N=2000 is latency-bound on the chain of 31 diagonal factorisations; 13.2 us per chain step, DESIGN.md par. 4.1; the larger sizes are timed in extras.configs (C4: N=5000, C5: N=10000: 44.8 TFLOP/s; N=16000: 53.4 TFLOP/s; profiles/r04_cholesky_sizes.txt)"}
             if args.config == "C3" and not shard:
                 t_cfg = time.perf_counter()
                 extras["configs"] = config_extras()
