@@ -712,8 +712,8 @@ class SurrogateModel(object):
                     centers = cand[torch.as_tensor(keep[:, 1].astype(np.int64), device=_dev())]
             else:
                 out = ut.utility_scan(self.gp, self._y, cand, self._bounds, algorithm=self.algorithm, y_best=y_best,
-                                      return_all=nref > 0)
-                _thetaN, u_best, idx = out[:3]
+                                      return_all=nref > 0, best_on_device=True)
+                _thetaN, u_best, idx = out[:3]              # (the incumbent stays on the device through the zoom stages)
                 centers = None
                 if idx >= 0 and nref > 0:
                     u_all = torch.where(torch.isfinite(out[3]), out[3], torch.full_like(out[3], float("inf")))
@@ -728,12 +728,14 @@ class SurrogateModel(object):
                     cloud = torch.minimum(torch.maximum(cloud, lo + 1e-12 * (hi - lo)), hi - 1e-12 * (hi - lo))
                     cloud[0] = torch.as_tensor(_thetaN, device=_dev())          # the incumbent can only be improved on
                     o2 = ut.utility_scan(self.gp, self._y, cloud, self._bounds, algorithm=self.algorithm, y_best=y_best,
-                                         return_all=True)
+                                         return_all=True, best_on_device=True)
                     if o2[2] >= 0 and o2[1] <= u_best:
-                        _thetaN, u_best = o2[0], o2[1]
+                        _thetaN, u_best = o2[0].clone(), o2[1]
                     u2 = torch.where(torch.isfinite(o2[3]), o2[3], torch.full_like(o2[3], float("inf")))
                     centers = cloud[torch.topk(-u2, min(ntop, nper)).indices]
                     width = 0.3 * width
+            if isinstance(_thetaN, torch.Tensor):
+                _thetaN = _thetaN.cpu().numpy()
             # optional continuous polish of the incumbent: L-BFGS-B with the closed-form GPU gradient
             npolish = int(kw.get("polish", 30))
             if idx >= 0 and npolish > 0:

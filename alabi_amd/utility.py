@@ -233,17 +233,19 @@ def utility_eval_device(algorithm, theta, bounds, mu, var, y_best=0.0):
     return u
 
 
-def utility_scan(gp, y, theta, bounds, algorithm="bape", y_best=0.0, return_all=False):
+def utility_scan(gp, y, theta, bounds, algorithm="bape", y_best=0.0, return_all=False, best_on_device=False):
     """Evaluate the acquisition function on M candidates on the GPU and return the arg-min.
 
     Returns (theta_best[d] numpy, u_best, index) and, with return_all, also (u, mu, var) device tensors.
+    best_on_device: theta_best stays a device tensor (a row of ``theta``; NaN row if no candidate is finite) -- the zoom stages of
+    find_next_point chain several scans and need the point on the host only once, at the end.
     Non-finite utilities (outside the box, var <= 0 for bape, ...) never win, as in
     utility.minimize_objective (utility.py:1149-1163).  index is -1 if no candidate is finite.
     """
     from .gp import _to_dev
     th = _to_dev(theta, 2)
     m, d = int(th.shape[0]), int(th.shape[1])
-    gp.predict_device(y, th[:1])  # makes sure K is factorised and alpha matches y
+    gp._require_computed(); gp._set_y(y)          # K is factorised and alpha matches y (no launch when y is unchanged)
     b = np.ascontiguousarray(np.asarray(bounds, dtype=np.float64).reshape(d, 2))
     u = mu = var = None
     if return_all:
@@ -256,7 +258,10 @@ def utility_scan(gp, y, theta, bounds, algorithm="bape", y_best=0.0, return_all=
                                        _lib.ptr(var), C.byref(best_val), C.byref(best_idx), _lib.current_stream())
     _lib.check(st, "alabi_utility_scan")
     idx = int(best_idx.value)
-    best_theta = th[idx].cpu().numpy() if idx >= 0 else np.full(d, np.nan)
+    if best_on_device:
+        best_theta = th[idx] if idx >= 0 else torch.full((d,), float("nan"), dtype=torch.float64, device=th.device)
+    else:
+        best_theta = th[idx].cpu().numpy() if idx >= 0 else np.full(d, np.nan)
     out = (best_theta, float(best_val.value), idx)
     return out + (u, mu, var) if return_all else out
 
