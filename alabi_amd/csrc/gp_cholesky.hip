@@ -893,6 +893,7 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
         constexpr int S = decltype(s_tag)::value;
         constexpr int c0 = 16 * S;
         if (!ct_flag_wait(11, S + 1, true)) { ok = false; return; }
+        if (w == 7) CT_LOGW(16 + 4 * S);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(linv, 0, 32768u, 0x00020000);   // the column's slab buffer
         ct_u32x4 v[8];                                         // every LDS read first (see tile_store_sc1); piece e = lane + 64 p_: row e >> 3 >= c0
         double dl = 1.0;
@@ -906,6 +907,7 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
 #pragma unroll
         for (int p_ = 2 * S; p_ < 8; ++p_) asm volatile("" : "+v"(v[p_]));
         if (w == 3) ct_flag_set(14, S + 1, lane);
+        if (w == 7) CT_LOGW(17 + 4 * S);
 #pragma unroll
         for (int p_ = 2 * S; p_ < 8; ++p_) {
             const int e = lane + 64 * p_;
@@ -914,7 +916,9 @@ __device__ __attribute__((noinline)) double ct_potrf_publish(int kb, int* info, 
         if (w == 3 && lane < 16)
             __hip_atomic_store(ct_g64(dinv + kb * 64 + c0 + lane), (unsigned long long)__double_as_longlong(potrf_dinv(dl)),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 7) CT_LOGW(18 + 4 * S);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (w == 7) CT_LOGW(19 + 4 * S);
         if (w == 7) ct_flag_set(10, S + 1, lane);
         else {
             if (eight && !ct_flag_wait(10, S + 1, true)) { ok = false; return; }
@@ -1873,6 +1877,12 @@ int launch_cholesky_tasks(alabi_gp* gp, hipStream_t s, int* launched) {
             const double n_ = k1 - k0 + 1;
             fprintf(stderr, "  relative to the END of the previous CHAIN's last recurrence: tiles in LDS %+.2f; slab 0 / 1 / 2 / 3 in LDS %+.2f %+.2f %+.2f %+.2f; solve + diag update done %+.2f; "
                             "factorisation starts %+.2f (the previous CHAIN's last inverse block drained at %+.2f)\n", t[7] / n_, t[0] / n_, t[1] / n_, t[2] / n_, t[3] / n_, t[4] / n_, t[5] / n_, t[6] / n_);
+        }
+        for (int sl = 0; sl < 3; ++sl) {
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (int k = k0; k <= k1; ++k) { a0 += 0.01 * (double)(h[k][16 + 4 * sl] - h[k][10 + sl]); a1 += 0.01 * (double)(h[k][17 + 4 * sl] - h[k][16 + 4 * sl]); a2 += 0.01 * (double)(h[k][18 + 4 * sl] - h[k][17 + 4 * sl]); a3 += 0.01 * (double)(h[k][19 + 4 * sl] - h[k][18 + 4 * sl]); }
+            const double n_ = k1 - k0 + 1;
+            fprintf(stderr, "  slab %d, storing wave 7: sees the recurrence done after %.2f, LDS reads %.2f, stores issued %.2f, drained %.2f\n", sl, a0 / n_, a1 / n_, a2 / n_, a3 / n_);
         }
         double per = 0, hop = 0;
         for (int k = k0; k <= k1; ++k) { per += 0.01 * (double)(h[k + 1][9] - h[k][9]); hop += 0.01 * (double)(h[k + 1][6] - h[k][14]); }
