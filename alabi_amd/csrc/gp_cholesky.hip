@@ -559,7 +559,7 @@ __device__ inline void ct_store_pair(__amdgpu_buffer_rsrc_t rs, int ld, int r, i
 // independent, each with its own tile versions, slab counters, status word and reciprocal diagonal.
 struct CholMat { double* A; double* dinv; double* linv; int* ver; int* sver; int* info; int ld, nb; };
 #define ALABI_CHOL_TASKS_MAX_NB 256   // default upper end of the one-launch task queue (N <= 16384); beyond: panels of 8 block columns
-#define ALABI_CHOL_W8_MIN_NB 16   // block columns from which the queue runs eight waves per workgroup (chol_tasks8_kernel)
+#define ALABI_CHOL_W8_MIN_NB 3    // block columns from which the queue runs eight waves per workgroup (chol_tasks8_kernel): every size it takes
 #define ALABI_CHOL_UPDATE4_MIN_NB 100 // block columns from which the far updates take 2 x 2 tiles per task (UPDATE4; below: UPDATE2)
 #define ALABI_CHOL_PLAIN_MIN 4   // block columns per UPDATE from which its operands are read with ordinary loads behind one acquire
 
@@ -1783,7 +1783,7 @@ static int chol_task_list(int nb, const CholTask** dev, int* count) {
 int cholesky_tasks_prepare(alabi_gp* gp, hipStream_t s, int* ctl_ints_out) {
     *ctl_ints_out = 0;
     const int nb = gp->Npad / 64;
-    // Default for 16..256 block columns (N = 961..16384; ALABI_CHOL_TASKS=0 / 1 forces it off / on for 3..256).  With the eight-wave
+    // Default for 3..256 block columns (N = 129..16384; ALABI_CHOL_TASKS=0 forces it off).  With the eight-wave
     // kernel of round 3 (from 40 block columns on): N = 5000 1.79 ms, 8192 5.08, 10000 8.5 (39.2 TFLOP/s), 11000 10.9 (panels of 8:
     // 12.6), 12000 13.6 (15.4), 14000 20.6 (22.9), 16000 29.7 (30.6) -- profiles/r03_cholesky_w8_vs_w4.txt.  Before that: measured
     // (tools/prof_chol_tasks.py, assembly included; round 3, updates over groups of block columns): N = 1024 0.33 ms (0.46 launch
@@ -1791,7 +1791,9 @@ int cholesky_tasks_prepare(alabi_gp* gp, hipStream_t s, int* ctl_ints_out) {
     // 10000 9.9 (10.8 panels of 8), 12000 15.9 (15.4), 16000 35.1 (30.5): from 11000 on the rank-512 panel path is ahead.
     const char* env = getenv("ALABI_CHOL_TASKS");
     const bool forced_on = env && env[0] == '1', forced_off = env && env[0] == '0';
-    if (nb < 3 || nb > 256 || forced_off || (!forced_on && (nb < 16 || nb > ALABI_CHOL_TASKS_MAX_NB))) return ALABI_OK;
+    // From 3 block columns on since the end of round 4 (tools/prof_chol_small.py, queue vs launch per step: N = 192 0.092 vs 0.112 ms, 512 0.155 vs
+    // 0.230, 960 0.249 vs 0.408 -- with the matrix-core panel solves the queue wins at every size; before, it started at 16 block columns).
+    if (nb < 3 || nb > 256 || forced_off || (!forced_on && nb > ALABI_CHOL_TASKS_MAX_NB)) return ALABI_OK;
     const size_t ctl_ints = 2 + (size_t)nb * nb + nb + 130;            // + 130: alignment + phase timers of an ALABI_CHOL_PROF build
     // behind the control words (8-byte aligned; filled with the tag by the assembly kernel): the slab buffers, [nb][4][64][16] doubles
     auto total_ints = [](size_t b) { return ((2 + b * b + b + 130 + 1) & ~(size_t)1) + b * 8192; };
