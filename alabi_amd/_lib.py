@@ -42,6 +42,7 @@ SIGNATURES = {
     "alabi_gp_predict": (_i, [_vp, _vp, _ll, _vp, _vp, _vp]),
     "alabi_gp_fit_predict": (_i, [_vp, _vp, _i, _vp, _vp, _ll, _vp, _pd, _vp]),
     "alabi_gp_predict_grad": (_i, [_vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp]),
+    "alabi_gp_predict_grad_point": (_i, [_vp, _vp, _vp, _vp]),
     "alabi_gp_logdet": (_i, [_vp, _pd, _vp]),
     "alabi_gp_nll": (_i, [_vp, _pd, _vp]),
     "alabi_gp_grad_log_likelihood": (_i, [_vp, _pd, _vp]),

@@ -136,6 +136,8 @@ int alabi_gp_destroy(alabi_gp* gp) {
     if (gp->Xa) (void)hipFree(gp->Xa);
     if (gp->xa_centre) (void)hipFree(gp->xa_centre);
     if (gp->host_status) (void)hipHostFree(gp->host_status);
+    if (gp->point_host) (void)hipHostFree(gp->point_host);
+    if (gp->point_dev) (void)hipFree(gp->point_dev);
     if (gp->y) (void)hipFree(gp->y);
     if (gp->alpha) (void)hipFree(gp->alpha);
     if (gp->dinv) (void)hipFree(gp->dinv);
@@ -304,6 +306,29 @@ int alabi_gp_predict_grad(alabi_gp* gp, const double* Xs, long long M, double* m
     if (!gp->computed || !gp->has_alpha) return ALABI_NOT_COMPUTED;
     if (M == 0) return ALABI_OK;
     return launch_predict_grad(gp, Xs, M, mu, var, dmu, dvar, as_stream(stream));
+}
+
+// One point in, its value and gradient out, everything on the host side: the evaluation an optimiser makes ~30 times per
+// active-learning iteration (the polish step of find_next_point).  Pinned staging buffers owned by the handle: one small copy in,
+// the three kernels, one small copy out, one synchronisation -- no tensor is created on the way.
+int alabi_gp_predict_grad_point(alabi_gp* gp, const double* x, double* out, void* stream) {
+    if (!gp || !x || !out) return ALABI_BAD_ARGUMENT;
+    if (!gp->computed || !gp->has_alpha) return ALABI_NOT_COMPUTED;
+    hipStream_t s = as_stream(stream);
+    const int d = gp->d, nres = 2 + 2 * d;
+    if (!gp->point_host) {
+        ALABI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&gp->point_host), (size_t)(3 + 3 * ALABI_MAX_DIM) * sizeof(double), hipHostMallocDefault));
+        ALABI_HIP_CHECK(hipMalloc(&gp->point_dev, (size_t)(3 + 3 * ALABI_MAX_DIM) * sizeof(double)));
+    }
+    for (int k = 0; k < d; ++k) gp->point_host[k] = x[k];
+    double* xd = gp->point_dev; double* res = gp->point_dev + d;          // res: mu, var, dmu[d], dvar[d]
+    ALABI_HIP_CHECK(hipMemcpyAsync(xd, gp->point_host, (size_t)d * sizeof(double), hipMemcpyHostToDevice, s));
+    int st = launch_predict_grad(gp, xd, 1, res, res + 1, res + 2, res + 2 + d, s);
+    if (st != ALABI_OK) return st;
+    ALABI_HIP_CHECK(hipMemcpyAsync(gp->point_host + d, res, (size_t)nres * sizeof(double), hipMemcpyDeviceToHost, s));
+    ALABI_HIP_CHECK(hipStreamSynchronize(s));
+    for (int k = 0; k < nres; ++k) out[k] = gp->point_host[d + k];
+    return ALABI_OK;
 }
 
 static int gp_reductions_to_host(alabi_gp* gp, double out[2], hipStream_t s) {

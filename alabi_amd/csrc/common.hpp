@@ -59,6 +59,8 @@ struct alabi_gp {
     long long gen = 0;  // bumped by every compute / set_y / set_hyper
     int last_pivot = 0;
     int factor_path = 0;      // alabi_gp_last_factor_path
+    double* point_host = nullptr;   // alabi_gp_predict_grad_point: pinned [3 + 3 d] (the point, then mu, var, dmu, dvar)
+    double* point_dev = nullptr;    // the same on the device
     // hyper-parameters (host copies)
     double mean = 0.0, log_wn = -12.0, log_amp = 0.0;
     alabi::KernelFn kf{0, 1.0};   // kernel family (+ alpha of the rational quadratic)

@@ -444,6 +444,16 @@ class HipGP:
     def predict_grad_host(self, y, t):
         """The same as NumPy arrays, brought back with ONE device-to-host copy (the polish step of find_next_point calls this ~30
         times per active-learning iteration: four separate copies cost more than the kernels)."""
+        if not isinstance(t, torch.Tensor) and np.size(t) == self.ndim:
+            # one point: host buffers on both sides, no tensor on the way (alabi_gp_predict_grad_point)
+            self._require_computed()
+            self._set_y(y)
+            d = self.ndim
+            x = np.ascontiguousarray(np.asarray(t, dtype=np.float64).reshape(d))
+            out = np.empty(2 + 2 * d, dtype=np.float64)
+            _lib.check(_lib.lib().alabi_gp_predict_grad_point(self._handle, x.ctypes.data, out.ctypes.data, _lib.current_stream()),
+                       "alabi_gp_predict_grad_point")
+            return out[0:1], out[1:2], out[2:2 + d].reshape(1, d), out[2 + d:].reshape(1, d)
         mu, var, dmu, dvar = self.predict_grad_device(y, t)
         m, d = int(mu.shape[0]), self.ndim
         h = self._last_grad_buf.cpu().numpy()

@@ -136,6 +136,10 @@ int alabi_gp_fit_predict(alabi_gp* gp, const double* X, int N, const double* y, 
  * All pointers are device pointers.  ALABI_HIP_ERROR when there is no room for the L^-1 cache. */
 int alabi_gp_predict_grad(alabi_gp* gp, const double* Xs, long long M, double* mu, double* var,
                           double* dmu, double* dvar, void* stream);
+/* The same for ONE point with host buffers on both sides -- the evaluation the polish step of find_next_point makes ~30 times per
+ * active-learning iteration (alabi/utility.py:1030-1163 calls the objective and its gradient point by point): x [d] in, out [2 + 2 d] =
+ * mu, var, dmu[d], dvar[d]; pinned staging buffers of the handle, one synchronisation. */
+int alabi_gp_predict_grad_point(alabi_gp* gp, const double* x /* host [d] */, double* out /* host [2 + 2 d] */, void* stream);
 
 /* solver.log_determinant and -gp.log_likelihood(y) -- alabi/core.py:1248; gp_utils.py:139.
  * Both SYNCHRONISE the stream and write one host double. */

@@ -624,6 +624,32 @@ def test_predict_mean_matrix_core_path(torch_gpu, monkeypatch, d, N, kernel, M):
     assert np.max(np.abs(mu_m[pick] - mu_o) / (np.abs(mu_o) + 1)) <= 1e-8
 
 
+def test_predict_grad_point_host_buffers(torch_gpu):
+    """alabi_gp_predict_grad_point (one point, host buffers on both sides: what the polish step of find_next_point calls per
+    evaluation, alabi/utility.py:1030-1163) returns exactly what the batched device entry returns for that point; several points
+    take the device route."""
+    import torch
+    from alabi_amd import HipGP
+    for N, d in ((90, 2), (700, 5), (2000, 10)):
+        X, y, h = make_problem(N, d, 300 + N)
+        g = HipGP(d, h["mean"], h["log_white_noise"], h["log_amp"], h["log_M"]); g.compute(X)
+        rng = np.random.RandomState(N)
+        pts = rng.uniform(-1.0, 1.0, (5, d))
+        ref = [t.cpu().numpy() for t in g.predict_grad_device(y, pts)]
+        for q in range(5):
+            for x in (pts[q], pts[q:q + 1], list(pts[q])):
+                mu, var, dmu, dvar = g.predict_grad_host(y, x)
+                assert mu.shape == (1,) and var.shape == (1,) and dmu.shape == (1, d) and dvar.shape == (1, d)
+                assert mu[0] == ref[0][q] and var[0] == ref[1][q]
+                np.testing.assert_array_equal(dmu[0], ref[2][q]); np.testing.assert_array_equal(dvar[0], ref[3][q])
+        many = g.predict_grad_host(y, pts)
+        for a, b in zip(many, ref):
+            np.testing.assert_array_equal(a, b)
+        y2 = y + 0.5                                          # a new y: alpha is recomputed before the point is evaluated
+        mu2 = g.predict_grad_host(y2, pts[0])[0][0]
+        assert mu2 == g.predict_grad_device(y2, pts[:1])[0].cpu().numpy()[0] and mu2 != ref[0][0]
+
+
 @pytest.mark.parametrize("N,panel", [(705, "4"), (1500, "4"), (1100, "2"), (3200, "4"), (2900, "8"), (1700, "6")])
 def test_cholesky_panel_path(torch_gpu, monkeypatch, N, panel):
     """Panels of 2 / 4 block columns with one rank-128 / rank-256 trailing update (syrk_panel_kernel, 128 x 128 tiles) and
