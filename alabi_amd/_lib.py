@@ -141,6 +141,17 @@ def host_doubles(values):
     return arr
 
 
+_raw_stream = None
+
+
 def current_stream():
+    """torch's current stream of the current device as a hipStream_t.  Through torch._C._cuda_getCurrentRawStream where it exists
+    (0.3 us; torch.cuda.current_stream().cuda_stream builds a Stream object: ~10 us, and every call into the library needs it --
+    it was 0.4 ms of a 4 ms active-learning iteration)."""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
