@@ -61,6 +61,7 @@ SIGNATURES = {
     "alabi_gp_n": (_i, [_vp, _pi]),
     "alabi_kernel_matrix": (_i, [_vp, _i, _vp, _i, _i, _i, _d, _d, _pd, _vp, _vp]),
     "alabi_utility_scan": (_i, [_vp, _i, _vp, _ll, _pd, _d, _vp, _vp, _vp, _pd, _pll, _vp]),
+    "alabi_utility_polish": (_i, [_vp, _i, _vp, _vp, _d, _i, _vp, _pd, _pi, _vp]),
     "alabi_utility_eval": (_i, [_i, _vp, _ll, _i, _pd, _d, _vp, _vp, _vp, _vp]),
     "alabi_ens_create": (_i, [_vp, _i, _i, _i, _pd, _ull, C.POINTER(_vp)]),
     "alabi_ens_destroy": (_i, [_vp]),

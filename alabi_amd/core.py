@@ -671,7 +671,8 @@ class SurrogateModel(object):
         obj_opt_method "scan" (default here): ``ncand`` uniform candidates in the scaled box are scored in
         one batched HIP pass (predict mean+variance -> utility -> arg-min), then ``refine`` zoom stages of
         ``nrefine`` candidates each around the ``ntop`` best; then the incumbent is polished by
-        L-BFGS-B with the closed-form GPU gradient (``optimizer_kwargs={"polish": maxiter}``, default 30, 0 = off).  Any scipy method name keeps
+        a projected L-BFGS with the closed-form GPU gradient (``optimizer_kwargs={"polish": maxiter}``, default 30, 0 = off;
+        ``"polish_method": "scipy"`` runs scipy's L-BFGS-B around the same evaluations instead).  Any scipy method name keeps
         the reference's multistart local optimisation with one GP prediction per objective call."""
         t0 = time.time()
         y_best = float(np.max(self._y))
@@ -740,7 +741,7 @@ class SurrogateModel(object):
             npolish = int(kw.get("polish", 30))
             if idx >= 0 and npolish > 0:
                 th_p, u_p = ut.polish_point(self.gp, self._y, _thetaN, self._bounds, algorithm=self.algorithm, y_best=y_best,
-                                            maxiter=npolish)
+                                            maxiter=npolish, method=str(kw.get("polish_method", "native")))
                 if u_p < u_best:
                     _thetaN, u_best = th_p, u_p
             self.last_acquisition_value = float(u_best) if idx >= 0 else np.nan
@@ -752,7 +753,7 @@ class SurrogateModel(object):
                 obj_fn = partial(self.utility, predict_gp=predict_gp, bounds=self._bounds, y_best=y_best)
             else:
                 obj_fn = partial(self.utility, predict_gp=predict_gp, bounds=self._bounds)
-            for k in ("ncand", "polish", "refine", "nrefine", "ntop"):
+            for k in ("ncand", "polish", "polish_method", "refine", "nrefine", "ntop"):
                 kw.pop(k, None)
             grad_obj_fn = None           # analytic gradient on the GPU (reference: core.py:1618-1625 passes grad_utility)
             if getattr(self, "use_grad_opt", True) and getattr(self, "grad_utility", None) is not None:

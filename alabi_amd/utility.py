@@ -300,11 +300,25 @@ def utility_value_and_grad(algorithm, mu, var, dmu, dvar, y_best=0.0, zeta=0.01)
     return float(u), g
 
 
-def polish_point(gp, y, theta0, bounds, algorithm="bape", y_best=0.0, maxiter=30):
-    """L-BFGS-B from ``theta0`` on the acquisition function with value and gradient from ONE device call per evaluation
-    (alabi_gp_predict_grad): the continuous-optimum step of utility.py:1030-1163 on top of a batched scan.
+def polish_point(gp, y, theta0, bounds, algorithm="bape", y_best=0.0, maxiter=30, method="native"):
+    """Bound-constrained quasi-Newton descent from ``theta0`` on the acquisition function with value and gradient from ONE device
+    call per evaluation (alabi_gp_predict_grad_point): the continuous-optimum step of utility.py:1030-1163 on top of a batched scan.
+    method "native" (default): the library's projected L-BFGS next to the kernels (alabi_utility_polish) -- through scipy an
+    evaluation cost 80 us at N = 100, 31 us of it device work, and the polish was 70 % of an active-learning iteration;
+    method "scipy": scipy's L-BFGS-B around predict_grad_host (the earlier implementation, kept for comparison).
     The box is shrunk by 1e-9 of its width because the reference's objective is +inf ON the boundary (utility.py:268-275).
     Returns (theta, u); never worse than the start."""
+    if method == "native":
+        gp._require_computed(); gp._set_y(y)
+        d = gp.ndim
+        x0n = np.ascontiguousarray(np.asarray(theta0, dtype=np.float64).reshape(d))
+        bn = np.ascontiguousarray(np.asarray(bounds, dtype=np.float64).reshape(d, 2))
+        xo = np.empty(d, dtype=np.float64)
+        uo = C.c_double(0.0); ne = C.c_int(0)
+        st = _lib.lib().alabi_utility_polish(gp.handle, _lib.UTILITY_CODES[algorithm], x0n.ctypes.data, bn.ctypes.data, float(y_best),
+                                             int(maxiter), xo.ctypes.data, C.byref(uo), C.byref(ne), _lib.current_stream())
+        _lib.check(st, "alabi_utility_polish")
+        return xo, float(uo.value)
     b = np.asarray(bounds, dtype=np.float64)
     eps = 1e-9 * (b[:, 1] - b[:, 0])
     box = np.column_stack([b[:, 0] + eps, b[:, 1] - eps])

@@ -179,6 +179,12 @@ int alabi_kernel_matrix(const double* X1, int n1, const double* X2, int n2, int 
 int alabi_utility_scan(alabi_gp* gp, int algo, const double* Xs, long long M,
                        const double* bounds, double y_best, double* u, double* mu_out,
                        double* var_out, double* best_val, long long* best_idx, void* stream);
+/* Continuous polish of an acquisition optimum: projected limited-memory BFGS from x0 inside the (open) box, value and gradient of the
+ * acquisition function from ONE alabi_gp_predict_grad_point per evaluation, the optimiser itself on the host beside it.  Stands for the
+ * local optimisation of alabi/utility.py:1030-1163 (scipy L-BFGS-B around one prediction per objective call) on top of the batched
+ * scan; never worse than x0.  bounds [d][2], x0 / x_out [d], all host; *nevals = evaluations made. */
+int alabi_utility_polish(alabi_gp* gp, int algo, const double* x0, const double* bounds, double y_best, int maxiter,
+                         double* x_out, double* u_out, int* nevals, void* stream);
 /* The epilogue alone on caller-supplied (mu, var): used by the parity tests. */
 int alabi_utility_eval(int algo, const double* Xs, long long M, int d, const double* bounds,
                        double y_best, const double* mu, const double* var, double* u,
