@@ -141,11 +141,22 @@ extern "C" int alabi_utility_polish(alabi_gp* gp, int algo, const double* x0, co
                 const bool fin = eval(xp, fp, gp_);
                 return (fin && *fp <= f + 1e-4 * dd) ? 1 : 0;
             };
-            for (int ls = 0; ls < 25; ++ls, t *= 0.5) {
+            for (int ls = 0; ls < 12; ++ls) {
                 double decr;
                 const int r = trial(t, xn, gn, &fn, &decr);
                 if (st != ALABI_OK) return st;
                 if (r < 0) break;
+                if (r == 0) {
+                    // next trial: the minimiser of the parabola through f, its slope along the projected step and the rejected value, kept
+                    // inside [0.1 t, 0.5 t]; a quarter of the step where the value was not finite
+                    double tn = 0.25 * t;
+                    if (std::isfinite(fn) && decr < 0.0) {
+                        const double curv = fn - f - decr;             // = (1/2) phi'' t^2 for a parabola along the step
+                        if (curv > 0.0) tn = std::fmin(std::fmax(-0.5 * decr / curv * t, 0.1 * t), 0.5 * t);
+                    }
+                    t = tn;
+                    continue;
+                }
                 if (r == 1) {
                     accepted = true;
                     if (ls == 0 && npairs == 0) {           // (a quasi-Newton step is taken as it is)

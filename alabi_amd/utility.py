@@ -318,6 +318,7 @@ def polish_point(gp, y, theta0, bounds, algorithm="bape", y_best=0.0, maxiter=30
         st = _lib.lib().alabi_utility_polish(gp.handle, _lib.UTILITY_CODES[algorithm], x0n.ctypes.data, bn.ctypes.data, float(y_best),
                                              int(maxiter), xo.ctypes.data, C.byref(uo), C.byref(ne), _lib.current_stream())
         _lib.check(st, "alabi_utility_polish")
+        gp._last_polish_nevals = int(ne.value)                    # (diagnostics: evaluations the polish made)
         return xo, float(uo.value)
     b = np.asarray(bounds, dtype=np.float64)
     eps = 1e-9 * (b[:, 1] - b[:, 0])
