@@ -320,12 +320,20 @@ int alabi_gp_predict_grad_point(alabi_gp* gp, const double* x, double* out, void
         ALABI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&gp->point_host), (size_t)(3 + 3 * ALABI_MAX_DIM) * sizeof(double), hipHostMallocDefault));
         ALABI_HIP_CHECK(hipMalloc(&gp->point_dev, (size_t)(3 + 3 * ALABI_MAX_DIM) * sizeof(double)));
     }
+    // Zero copy: the kernels read the point from and write the 2 + 2 d results to the pinned (device-visible, coherent) staging buffer
+    // themselves -- two copy operations fewer on the stream per evaluation (ALABI_POINT_COPY=1: explicit copies, the earlier form).
+    static const bool copies = [] { const char* e = getenv("ALABI_POINT_COPY"); return e && e[0] == '1'; }();
     for (int k = 0; k < d; ++k) gp->point_host[k] = x[k];
-    double* xd = gp->point_dev; double* res = gp->point_dev + d;          // res: mu, var, dmu[d], dvar[d]
-    ALABI_HIP_CHECK(hipMemcpyAsync(xd, gp->point_host, (size_t)d * sizeof(double), hipMemcpyHostToDevice, s));
-    int st = launch_predict_grad(gp, xd, 1, res, res + 1, res + 2, res + 2 + d, s);
-    if (st != ALABI_OK) return st;
-    ALABI_HIP_CHECK(hipMemcpyAsync(gp->point_host + d, res, (size_t)nres * sizeof(double), hipMemcpyDeviceToHost, s));
+    int st;
+    if (copies) {
+        double* xd = gp->point_dev; double* res = gp->point_dev + d;      // res: mu, var, dmu[d], dvar[d]
+        ALABI_HIP_CHECK(hipMemcpyAsync(xd, gp->point_host, (size_t)d * sizeof(double), hipMemcpyHostToDevice, s));
+        if ((st = launch_predict_grad(gp, xd, 1, res, res + 1, res + 2, res + 2 + d, s)) != ALABI_OK) return st;
+        ALABI_HIP_CHECK(hipMemcpyAsync(gp->point_host + d, res, (size_t)nres * sizeof(double), hipMemcpyDeviceToHost, s));
+    } else {
+        double* res = gp->point_host + d;
+        if ((st = launch_predict_grad(gp, gp->point_host, 1, res, res + 1, res + 2, res + 2 + d, s)) != ALABI_OK) return st;
+    }
     ALABI_HIP_CHECK(hipStreamSynchronize(s));
     for (int k = 0; k < nres; ++k) out[k] = gp->point_host[d + k];
     return ALABI_OK;
