@@ -733,23 +733,26 @@ class SurrogateModel(object):
                 _thetaN, u_best, idx = out[:3]              # (the incumbent stays on the device through the zoom stages)
                 centers = None
                 if idx >= 0 and nref > 0:
-                    u_all = torch.where(torch.isfinite(out[3]), out[3], torch.full_like(out[3], float("inf")))
-                    centers = cand[torch.topk(-u_all, min(ntop, ncand)).indices]
+                    u_all = torch.nan_to_num(out[3], nan=float("inf"), posinf=float("inf"), neginf=float("inf"))
+                    centers = cand[torch.topk(u_all, min(ntop, ncand), largest=False).indices]
             # Zoom stages (stand in for the reference's local optimiser, utility.py:1030-1163, at batched-scan cost):
             # Gaussian clouds of shrinking width around the best candidates so far, scored in one pass each.
             if idx >= 0 and nref > 0:
+                # (few launches per stage: at small N a stage is launch latency -- one fused multiply-add for the cloud, one clamp
+                # against precomputed inner bounds, nan_to_num instead of isfinite / full_like / where, topk on the values themselves)
                 width = 0.08 * (hi - lo)
+                lo_in, hi_in = lo + 1e-12 * (hi - lo), hi - 1e-12 * (hi - lo)
                 for _ in range(nref):
                     rep = centers[torch.randint(0, centers.shape[0], (nper,), device=_dev(), generator=gen)]
-                    cloud = rep + width * torch.randn((nper, self.ndim), dtype=torch.float64, device=_dev(), generator=gen)
-                    cloud = torch.minimum(torch.maximum(cloud, lo + 1e-12 * (hi - lo)), hi - 1e-12 * (hi - lo))
+                    cloud = torch.addcmul(rep, torch.randn((nper, self.ndim), dtype=torch.float64, device=_dev(), generator=gen), width)
+                    cloud = torch.clamp(cloud, min=lo_in, max=hi_in)
                     cloud[0] = torch.as_tensor(_thetaN, device=_dev())          # the incumbent can only be improved on
                     o2 = ut.utility_scan(self.gp, self._y, cloud, self._bounds, algorithm=self.algorithm, y_best=y_best,
                                          return_all=True, best_on_device=True)
                     if o2[2] >= 0 and o2[1] <= u_best:
                         _thetaN, u_best = o2[0].clone(), o2[1]
-                    u2 = torch.where(torch.isfinite(o2[3]), o2[3], torch.full_like(o2[3], float("inf")))
-                    centers = cloud[torch.topk(-u2, min(ntop, nper)).indices]
+                    u2 = torch.nan_to_num(o2[3], nan=float("inf"), posinf=float("inf"), neginf=float("inf"))
+                    centers = cloud[torch.topk(u2, min(ntop, nper), largest=False).indices]
                     width = 0.3 * width
             if isinstance(_thetaN, torch.Tensor):
                 _thetaN = _thetaN.cpu().numpy()
