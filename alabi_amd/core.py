@@ -834,11 +834,13 @@ class SurrogateModel(object):
                 res["gp_hyperparameter_opt_iteration"].append(ii + first_iter)
                 if save_progress:
                     self.save()
+            y_now = var_y_now = None                        # (self.y() un-scales the whole training set: once per iteration)
             try:
                 _yp = self.gp.predict(_y_prop, _theta_prop, return_cov=False, return_var=False)
                 yp = self.y_scaler.inverse_transform(_yp.reshape(-1, 1)).flatten()
-                training_mse = np.mean((self.y() - yp) ** 2)
-                training_scaled_mse = training_mse / np.var(self.y())
+                y_now = self.y(); var_y_now = np.var(y_now)
+                training_mse = np.mean((y_now - yp) ** 2)
+                training_scaled_mse = training_mse / var_y_now
             except Exception as e:  # noqa: BLE001
                 print(f"Warning: Error evaluating GP training error at iteration {ii + first_iter}: {e}")
                 training_mse = training_scaled_mse = np.nan
@@ -849,7 +851,7 @@ class SurrogateModel(object):
                     yt = self.y_scaler.inverse_transform(_yt.reshape(-1, 1)).flatten()
                     yt_true = self.y_scaler.inverse_transform(self._y_test.reshape(-1, 1)).flatten()
                     test_mse = np.mean((yt_true - yt) ** 2)
-                    test_scaled_mse = test_mse / np.var(self.y())
+                    test_scaled_mse = test_mse / (var_y_now if var_y_now is not None else np.var(self.y()))
                 except Exception as e:  # noqa: BLE001
                     print(f"Warning: Error evaluating GP test error at iteration {ii + first_iter}: {e}")
             res["iteration"].append(ii + first_iter)
