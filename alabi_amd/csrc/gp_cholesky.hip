@@ -1526,10 +1526,10 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
             }
         } else if (type == 1) {
             // ---------------- TRSM(i, k)
-            {
-                TileRegs<NT> rb;
-                tile_fetch<NT>(rb, A + (size_t)(ti * 64) * ld + tk * 64, ld, tid);
-                tile_put<NT>(T1, rb, tid);
+            {   // (16-byte coherent loads: half the instructions of the 8-byte form, and the faster rate per byte)
+                TileRegs16<NT> rb;
+                tile_fetch16<false, NT>(rb, arsrc, (unsigned)(ti * 64) * (unsigned)ld * 8u + (unsigned)tk * 512u, ld, tid);
+                tile_put16<NT>(T1, rb, tid);
             }
             if (!ct_solve<NT, false, !BATCH>(ld, linv + (size_t)tk * 4096, sver + tk, err, spin_limit, ntasks,
                                      A + (size_t)(ti * 64) * ld + tk * 64)) return;
@@ -1548,10 +1548,10 @@ __device__ __forceinline__ void chol_tasks_body(double* __restrict__ A_, int ld_
 #endif
             if (tk > 0) {
                 {
-                    TileRegs<NT> rb, rc;
-                    tile_fetch<NT>(rb, A + (size_t)(tk * 64) * ld + (tk - 1) * 64, ld, tid);
-                    tile_fetch<NT>(rc, D, ld, tid);
-                    tile_put<NT>(T1, rb, tid); tile_put<NT>(T2, rc, tid);
+                    TileRegs16<NT> rb, rc;
+                    tile_fetch16<false, NT>(rb, arsrc, (unsigned)(tk * 64) * (unsigned)ld * 8u + (unsigned)(tk - 1) * 512u, ld, tid);
+                    tile_fetch16<false, NT>(rc, arsrc, (unsigned)(tk * 64) * (unsigned)ld * 8u + (unsigned)tk * 512u, ld, tid);
+                    tile_put16<NT>(T1, rb, tid); tile_put16<NT>(T2, rc, tid);
                 }
 #ifdef ALABI_CHOL_PROF
                 p1 = __builtin_amdgcn_s_memrealtime();
